@@ -1,0 +1,77 @@
+/* buildEngine-hip.h -- load step of the HIP engine: CSV -> rows -> per-column
+ * device buffers (+ order-preserving dictionaries for the 7 string columns).
+ *
+ * Same role and naming as the reference's include/buildEngine-omp.h:30-35;
+ * CSV rules follow engine/serial/buildEngine-serial.c:70-221 exactly
+ * (SURVEY.md App. A.5): header line skipped, 1024-byte fgets window, quoted
+ * fields with "" escape, missing trailing fields stay zero.
+ */
+#ifndef BUILDENGINE_HIP_H
+#define BUILDENGINE_HIP_H
+
+#include "bplus.h"
+#include "executeEngine-hip.h"
+#include "logType.h"
+#include "recordSchema.h"
+#include "pqps_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Column order of `record` / the CSV. */
+enum {
+    HIPCOL_COMMAND_ID = 0, HIPCOL_RAW_COMMAND, HIPCOL_BASE_COMMAND, HIPCOL_SHELL_TYPE,
+    HIPCOL_EXIT_CODE, HIPCOL_TIMESTAMP, HIPCOL_SUDO_USED, HIPCOL_WORKING_DIRECTORY,
+    HIPCOL_USER_ID, HIPCOL_USER_NAME, HIPCOL_HOST_NAME, HIPCOL_RISK_LEVEL,
+    HIPCOL_COUNT
+};
+
+/* Sorted (strcmp byte order) distinct values of one string column. */
+struct hipDictionary {
+    int count;
+    const char **values;     /* count pointers into `storage`, ascending */
+    char *storage;
+};
+
+/* One B+-tree replacement: device permutation + sorted keys. */
+struct hipIndex {
+    int column;              /* HIPCOL_*                                   */
+    int key_kind;            /* 0 unsigned, 1 signed                       */
+    uint32_t *perm_dev;      /* n rows, (key asc, row desc)                */
+    void *keys_dev;          /* n keys, column width                       */
+};
+
+/* Device-resident table; hangs off engineS.record_block. */
+struct hipTable {
+    pqps_ctx *ctx;
+    uint64_t n_rows;
+    uint64_t capacity_rows;                      /* allocation, multiple of PQPS_TILE_ROWS */
+    pqps_column col[HIPCOL_COUNT];               /* device buffers                         */
+    struct hipDictionary dict[HIPCOL_COUNT];     /* string columns only                    */
+    struct hipIndex *index;                      /* engine->num_indexes entries            */
+    uint32_t *ids_dev;                           /* result scratch, capacity_ids u32       */
+    uint64_t capacity_ids;
+    uint64_t *count_dev;                         /* 4 x u64: count, range[2], spare        */
+    record *row_block;                           /* contiguous host rows (all_records[i] point in) */
+};
+
+/* CSV -> contiguous block of records + pointer array (reference signature of
+ * getAllRecordsFromFileOMP, buildEngine-omp.h:31). */
+record **getAllRecordsFromFileHIP(const char *filepath, int *num_records, void **record_block_out);
+/* Parses one CSV line into a freshly calloc'd record (buildEngine-serial.c:159). */
+record *getRecordFromLineHIP(char *line);
+/* Same, into caller storage (zeroed first). */
+void fillRecordFromLineHIP(record *dst, const char *line);
+FieldType mapAttributeTypeHIP(int attributeType);
+/* Builds the device index for one attribute and appends it to the engine. */
+bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeType);
+
+/* rows -> columns -> device.  Creates engine->record_block. */
+bool buildDeviceTableHIP(struct engineS *engine);
+void destroyDeviceTableHIP(struct engineS *engine);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUILDENGINE_HIP_H */

@@ -1,0 +1,189 @@
+/* pqps_hip.h -- thin C-ABI shim over the hand-written gfx950 kernels.
+ *
+ * This is the lowest drop-in boundary of the HIP backend: plain pointers and
+ * sizes, no C++ / torch types.  Everything behind it lives in ONE hipcc
+ * translation unit (csrc/pqps_hip.hip).  The C11 engine
+ * (engine/hip/executeEngine-hip.c) and the Python harness (ctypes) are its
+ * only callers.
+ *
+ * What each entry point replaces in the reference (Jairik/Parallel-Query-
+ * Processing-System, paths relative to its root):
+ *
+ *   pqps_filter_scan    linearSearchRecords over engine->all_records
+ *                       (engine/serial/executeEngine-serial.c:854-878, called
+ *                       from :466) with evaluateWhereClause :292-316 /
+ *                       checkCondition :251-289 / CMP_* :18-123 fused in.
+ *   pqps_filter_gather  linearSearchRecords over the index candidates
+ *                       (executeEngine-serial.c:471) -- order preserving.
+ *   pqps_filter_count   COUNT(*): resultSetS.numRecords without the ID list
+ *                       (MPI shape: MPI_Allreduce at engine/mpi/executeEngine-mpi.c:745).
+ *   pqps_filter_flags   the per-row flag array of DELETE
+ *                       (engine/omp/executeEngine-omp.c:708-732, mpi :726-741).
+ *   pqps_index_build    loadIntoBplusTree (engine/serial/buildEngine-serial.c:41-62)
+ *                       -- as a permutation sorted (key asc, row desc), the
+ *                       leaf order of engine/bplus.c:282-314,471-490.
+ *   pqps_index_probe    findLeaf + the leaf walk of findRange (bplus.c:282-358).
+ *   pqps_partition      the block partition of engine/mpi/executeEngine-mpi.c:703-715.
+ *
+ * All functions return 0 on success or a negative PQPS_E* code; the text of
+ * the last error of the calling thread is at pqps_last_error().
+ * Device pointers are plain `void *` (hipMalloc / torch tensor data_ptr).
+ * `stream` is a hipStream_t passed as void*; NULL = the context's own stream.
+ */
+#ifndef PQPS_HIP_H
+#define PQPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQPS_OK            0
+#define PQPS_EINVAL       -1   /* bad argument (shape, width, alignment, capacity) */
+#define PQPS_EHIP         -2   /* a HIP runtime call failed                        */
+#define PQPS_ENOMEM       -3
+#define PQPS_ENODEVICE    -4   /* no gfx950 device visible                         */
+#define PQPS_EOVERFLOW    -5   /* out_ids capacity too small for the matches       */
+
+#define PQPS_MAX_COLUMNS  12   /* columns of `record` (include/logType.h)          */
+#define PQPS_MAX_LEAVES   32   /* leaf comparisons in one WHERE tree               */
+#define PQPS_TT_LEAVES     6   /* <= 6 leaves: 64-entry truth table path           */
+#define PQPS_TILE_ROWS  4096   /* rows one workgroup handles per look-back tile    */
+
+/* One device-resident column.  `width` in {1,2,4,8} bytes per row; values are
+ * compared as unsigned after the host has biased signed columns (see
+ * pqps_leaf).  `data` must be 16-byte aligned. */
+typedef struct pqps_column {
+    const void *data;
+    uint32_t width;
+    uint32_t reserved;
+} pqps_column;
+
+/* One leaf comparison, normalised by the host to an unsigned window test
+ *      hit = ((value - lo) <= span) XOR negate            (mod 2^w arithmetic)
+ * which covers =, !=, <, <=, >, >= on u64 / i32 / bool / dictionary codes
+ * (signed i32 windows work unchanged in two's complement). */
+typedef struct pqps_leaf {
+    uint32_t column;          /* index into the pqps_column array of the call */
+    uint32_t negate;          /* 0 or 1                                       */
+    uint64_t lo;
+    uint64_t span;
+} pqps_leaf;
+
+/* Jump-table form of the short-circuit evaluation of the WHERE tree
+ * (executeEngine-serial.c:292-316): after leaf k, go to on_true[k] /
+ * on_false[k]; targets are a later leaf index, PQPS_ACCEPT or PQPS_REJECT. */
+#define PQPS_ACCEPT 0xFE
+#define PQPS_REJECT 0xFF
+
+typedef struct pqps_predicate {
+    uint32_t n_leaves;                       /* 0: constant predicate (truth bit 0) */
+    uint32_t n_columns;                      /* columns referenced, <= 12            */
+    uint64_t truth;                          /* truth table over leaf bits, n<=6     */
+    pqps_leaf leaf[PQPS_MAX_LEAVES];         /* sorted by `column`                   */
+    uint8_t on_true[PQPS_MAX_LEAVES];        /* in ORIGINAL evaluation order ...     */
+    uint8_t on_false[PQPS_MAX_LEAVES];
+    uint8_t order[PQPS_MAX_LEAVES];          /* ... order[i] = leaf slot of step i   */
+} pqps_predicate;
+
+typedef struct pqps_ctx pqps_ctx;
+
+const char *pqps_last_error(void);
+
+/* Context = device ordinal + stream + look-back scratch (grown on demand). */
+int  pqps_ctx_create(int device, pqps_ctx **out);
+void pqps_ctx_destroy(pqps_ctx *ctx);
+int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
+int  pqps_device_count(void);
+/* Fills name (<=63 chars), CU count and total HBM bytes of the ctx device. */
+int  pqps_device_info(pqps_ctx *ctx, char *name64, int *compute_units, uint64_t *hbm_bytes);
+
+/* Plain device memory helpers so a C host needs no HIP headers. */
+int  pqps_malloc(pqps_ctx *ctx, size_t bytes, void **dptr);
+int  pqps_free(pqps_ctx *ctx, void *dptr);
+int  pqps_memset(pqps_ctx *ctx, void *dptr, int value, size_t bytes, void *stream);
+int  pqps_upload(pqps_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int  pqps_download(pqps_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+
+/* Scan mode.  Evaluates `pred` on rows [0, n_rows) of `cols` and writes the
+ * matching row IDs (row + id_base, u32) in ASCENDING row order to out_ids and
+ * their number to *out_count (device u64).  Asynchronous on `stream`.
+ * Columns must be readable up to n_rows rounded up to 16 bytes. */
+int pqps_filter_scan(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                     uint64_t n_rows, uint32_t id_base, const pqps_predicate *pred,
+                     uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
+                     void *stream);
+
+/* COUNT(*) only: no ID list, one u64. */
+int pqps_filter_count(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                      uint64_t n_rows, const pqps_predicate *pred,
+                      uint64_t *out_count, void *stream);
+
+/* Per-row byte flags (1 = match), the DELETE / MPI_Allgatherv shape. */
+int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                      uint64_t n_rows, const pqps_predicate *pred,
+                      uint8_t *out_flags, uint64_t *out_count, void *stream);
+
+/* Index mode.  Candidates are cand[range[0] .. range[1]) (device u32 row
+ * numbers, `range` = 2 device u64 as written by pqps_index_probe); rows that
+ * satisfy `pred` are APPENDED, candidate order preserved, at
+ * out_ids[*out_count ...], and *out_count (device u64) is advanced -- several
+ * probes concatenate without a host round trip (executeEngine-serial.c:444-448). */
+int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                       const uint32_t *cand, const uint64_t *range, uint64_t max_candidates,
+                       uint32_t id_base, const pqps_predicate *pred,
+                       uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
+                       void *stream);
+
+/* Builds perm[0..n) = row numbers sorted by (key ascending, row DESCENDING)
+ * and sorted_keys[0..n) (same width as the column).  key_kind: 0 = unsigned,
+ * 1 = signed i32. */
+int pqps_index_build(pqps_ctx *ctx, const pqps_column *col, uint64_t n_rows, int key_kind,
+                     uint32_t *perm, void *sorted_keys, void *stream);
+
+/* range[0] = first position with key >= key_lo, range[1] = first position with
+ * key > key_hi (inclusive window, findRange semantics); keys as raw 64-bit
+ * patterns, compared signed when key_kind == 1. */
+int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int key_kind,
+                     uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
+                     uint64_t *range, void *stream);
+
+/* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */
+void pqps_partition(uint64_t n_rows, int world, int rank, uint64_t *start, uint64_t *count);
+
+/* Seeded on-device generator of the commands_* schema (SURVEY.md App. B /
+ * generate_commands.py distributions); rows [row0, row0+n) of the global
+ * table.  Any output pointer may be NULL.  `user_cdf` = 2000 u32 thresholds,
+ * `user_shell` = 2000 u8 (both device), built by pqps_synth_user_tables. */
+typedef struct pqps_synth_cols {
+    uint64_t *command_id;
+    int32_t  *exit_code;
+    int32_t  *user_id;
+    int32_t  *risk_level;
+    uint8_t  *sudo_used;
+    uint8_t  *shell_code;     /* rank in {"bash","fish","sh","zsh"}        */
+    uint16_t *user_code;      /* rank of "student<id>" == user_id - 1000   */
+    uint8_t  *host_code;      /* rank among the 16 host names              */
+    uint8_t  *base_code;      /* rank among 111 base commands (uniform)    */
+} pqps_synth_cols;
+
+#define PQPS_SYNTH_USERS 2000
+void pqps_synth_user_tables(uint64_t seed, uint32_t *cdf_host, uint8_t *shell_host);
+int  pqps_synth_generate(pqps_ctx *ctx, uint64_t seed, uint64_t row0, uint64_t n,
+                         const uint32_t *user_cdf_dev, const uint8_t *user_shell_dev,
+                         const pqps_synth_cols *out, void *stream);
+/* CPU twin of the generator (same bits), used by tests and the CPU baseline. */
+void pqps_synth_generate_host(uint64_t seed, uint64_t row0, uint64_t n,
+                              const uint32_t *user_cdf, const uint8_t *user_shell,
+                              const pqps_synth_cols *out);
+
+/* Streaming-read probe: sums `bytes` of device memory with 16 B/lane loads;
+ * used by bench.py to report the empirical HBM read ceiling next to 8 TB/s. */
+int pqps_read_probe(pqps_ctx *ctx, const void *data, uint64_t bytes, uint64_t *out_sum, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQPS_HIP_H */

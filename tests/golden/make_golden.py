@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the authoring container: it needs oracle/_ref/libqpeseq_ref.so
+(the reference compiled from /root/reference by oracle/Makefile) and, for the
+one-off creation of commands_2k.csv, the reference's own data generator
+(/root/reference/data-generation/generate_commands.py, run as a subprocess).
+The generator is unseeded, so the CSV it wrote is COMMITTED and never
+regenerated; everything else here is deterministic given the two CSVs.
+
+Outputs (all data: inputs + what the reference answered):
+  commands_2k.csv, edge_cases.csv          inputs
+  select_golden.json     SELECT cases: where-list as parsed by the reference,
+                         result row numbers, sha256 of every projected cell
+  parse_golden.json      SQL text -> reference token stream / ParsedSQL / where list
+  records_golden.json    CSV -> the 1040-byte records the reference loaded
+  index_order_golden.json  leaf order of the reference's B+ trees
+  print_golden.json      printTable() text for a few queries
+Cases whose index candidates exceed num_records are never sent to the
+reference (it overflows its buffer, executeEngine-serial.c:342,447); they are
+recorded with "pinned": false and the oracle's answer.
+"""
+import base64
+import hashlib
+import json
+import pathlib
+import subprocess
+import sys
+import tempfile
+import zlib
+
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
+import qpelib as q  # noqa: E402
+
+REF_GEN = pathlib.Path("/root/reference/data-generation/generate_commands.py")
+HEADER = ("command_id,raw_command,base_command,shell_type,exit_code,timestamp,sudo_used,"
+          "working_directory,user_id,user_name,host_name,risk_level")
+
+INDEX_CONFIGS = {
+    "none": [],
+    "default": q.DEFAULT_INDEXES,                      # connectEngine.c:48-62
+    "cmdid": [("command_id", 0)],                      # tests/serial-SELECT-test.c:149
+    "risk": [("risk_level", 1)],                       # tests/duplicate-test.c:29-31
+    "risk_twice": [("risk_level", 1), ("risk_level", 1)],
+}
+
+# (select list, where text or None).  Shapes: sample-queries.txt (S1..S8),
+# tests/serial-SELECT-test.c:169-185 (T*), SURVEY App. A (A*), quirks (Q*).
+SELECT_CASES = [
+    ("S1", "command_id, base_command, sudo_used, user_name, timestamp", 'sudo_used = FALSE AND user_name = "student1030"'),
+    ("S2", "command_id, raw_command, user_name, risk_level, timestamp", "sudo_used = TRUE AND risk_level > 2"),
+    ("S3", "raw_command, exit_code, timestamp, sudo_used, user_name, risk_level", "risk_level > 3"),
+    ("S4", "*", "risk_level = 5"),
+    ("S7", "command_id, raw_command, risk_level, exit_code", 'sudo_used = TRUE OR (risk_level = 5 AND shell_type = "bash")'),
+    ("S8", "user_name, working_directory, base_command", 'user_id = 1001 OR (user_name = "student1002" AND shell_type = "zsh")'),
+    ("T_all", "*", None),
+    ("T_proj", "command_id, user_name", None),
+    ("T_risk", "*", "risk_level > 2"),
+    ("T_shell", "command_id, shell_type", "shell_type = 'bash'"),
+    ("T_and", "command_id, risk_level, sudo_used", "risk_level > 2 AND sudo_used = 1"),
+    ("T_exit", "command_id, exit_code", "exit_code = 0"),
+    ("A_dup", "command_id, risk_level, exit_code", "risk_level >= 4 AND exit_code = 0"),
+    ("A_orloss1", "command_id, risk_level, user_name", 'risk_level = 5 OR user_name = "student1030"'),
+    ("A_orloss2", "command_id, risk_level, user_name", 'user_name = "student1030" OR risk_level = 5'),
+    ("A_neq", "command_id, risk_level", "risk_level != 3"),
+    ("A_cid_lt", "command_id", "command_id < 10"),
+    ("A_cid_ge", "command_id", "command_id >= 1990"),
+    ("A_cid_eq", "command_id, raw_command", "command_id = 77"),
+    ("A_cid_ne", "command_id", "command_id != 5"),
+    ("A_cid_gt_le", "command_id", "command_id > 100 AND command_id <= 110"),
+    ("A_uid", "command_id, user_id", "user_id = 1001"),
+    ("A_uid_range", "command_id, user_id", "user_id >= 1010 AND user_id < 1020"),
+    ("A_str_range", "command_id, user_name", 'user_name >= "student1050" AND user_name < "student1060"'),
+    ("A_ts", "command_id, timestamp", 'timestamp > "2026-01-01"'),
+    ("A_base_le", "command_id, base_command", 'base_command <= "cat"'),
+    ("A_host_ne", "command_id, host_name", 'host_name != "labpc-01"'),
+    ("A_wd", "command_id, working_directory", 'working_directory = "/tmp"'),
+    ("A_raw", "command_id, raw_command", 'raw_command = "pwd"'),
+    ("A_raw_gt", "command_id", 'raw_command > "sudo"'),
+    ("A_shell_lt", "command_id, shell_type", 'shell_type < "fish"'),
+    ("Q_uid_str", "command_id", 'user_id = "1001"'),
+    ("Q_sudo_1", "command_id", "sudo_used = 1"),
+    ("Q_sudo_true_lc", "command_id", "sudo_used = true"),
+    ("Q_sudo_yes", "command_id", "sudo_used = 'yes'"),
+    ("Q_sudo_gt", "command_id", "sudo_used > FALSE"),
+    ("Q_sudo_ne", "command_id", "sudo_used != TRUE"),
+    ("Q_cid_max", "command_id", "command_id = 18446744073709551615"),
+    ("Q_cid_big", "command_id", "command_id <= 99999999999999999999"),
+    ("Q_exit_gt", "command_id, exit_code", "exit_code > 100"),
+    ("Q_exit_ne0", "command_id, exit_code", "exit_code != 0"),
+    ("Q_unknown_attr", "command_id", "nonexistent = 5"),
+    ("Q_unknown_or", "command_id", "nonexistent = 5 OR risk_level = 5"),
+    ("Q_unknown_col", "bogus, command_id", "risk_level = 5"),
+    ("Q_noop", "command_id", "risk_level 5"),                       # missing operator -> "="
+    ("N_paren_all", "command_id", "(risk_level > 3 AND user_id = 1001)"),
+    ("N_two_subs", "command_id", "(risk_level > 3) OR (user_id = 1001)"),
+    ("N_mid", "command_id", "sudo_used = TRUE AND (risk_level = 4 OR risk_level = 5) AND exit_code != 0"),
+    ("N_deep", "command_id", "((risk_level = 5))"),
+    ("N_lead_sub", "command_id", '(risk_level = 5 OR risk_level = 4) AND shell_type = "zsh"'),
+    ("N_sub_or_idx", "command_id", "(sudo_used = TRUE AND exit_code = 0) OR risk_level = 5"),
+    ("R_and_or", "command_id", "risk_level = 1 AND exit_code != 0 OR sudo_used = TRUE"),
+    ("R_or_and", "command_id", "sudo_used = TRUE OR risk_level = 1 AND exit_code != 0"),
+    ("R_three_or", "command_id", "risk_level = 5 OR risk_level = 4 OR user_id = 1001"),
+    ("R_four", "command_id", 'sudo_used = FALSE AND risk_level >= 2 AND exit_code = 0 AND shell_type = "zsh"'),
+    ("W_order_by", "command_id", "risk_level = 5 ORDER BY command_id DESC"),
+    ("W_none_match", "command_id", "risk_level > 7"),
+    ("W_all_match", "command_id", "risk_level >= 1"),
+]
+
+# configs each case runs under on commands_2k.csv
+CASE_CONFIGS = ["none", "default"]
+EXTRA_CONFIGS = {"T_all": ["cmdid"], "T_risk": ["cmdid", "risk", "risk_twice"], "T_shell": ["cmdid"],
+                 "T_and": ["cmdid"], "T_exit": ["cmdid"], "S3": ["risk", "risk_twice"], "A_neq": ["risk"]}
+
+PARSE_CASES = [
+    "SELECT * FROM Commands",
+    "select command_id from commands where risk_level > 3",
+    "SELECT a, b ,c FROM t WHERE x >= 10 AND y <= 'abc' OR z != \"q r\";",
+    "# -- Sample 1:\nSELECT command_id, base_command, sudo_used, user_name, timestamp\nFROM Commands\nWHERE sudo_used = FALSE AND user_name = \"student1030\"",
+    "SELECT * FROM c WHERE risk_level = 1 and exit_code = 0",          # lowercase and: not a keyword
+    "SELECT * FROM c WHERE risk_level = 1 or exit_code = 0",           # lowercase or: keyword
+    "SELECT * FROM c WHERE a = TRUE AND b = false AND c = True",
+    "SELECT * FROM c WHERE a = -5",                                     # no negative literals
+    "SELECT * FROM c WHERE a = 3.14",
+    "SELECT * FROM c WHERE a = 'it''s'",
+    "SELECT * FROM c WHERE a = 'unterminated",
+    "SELECT * FROM c WHERE (a = 1 AND (b = 2 OR c = 3)) OR d = 4",
+    "SELECT * FROM c WHERE a = 1 AND b = 2 AND c = 3 AND d = 4",
+    "SELECT * FROM c WHERE ((a = 1) AND (b = 2)) AND ((c = 3))",
+    "SELECT * FROM c WHERE a 5",
+    "SELECT * FROM c WHERE a = 1 ORDER BY b DESC",
+    "SELECT * FROM c WHERE a = 1 ORDER BY b ASC",
+    "SELECT * FROM c ORDER BY b",
+    "SELECT x FROM c WHERE a = 1 -- trailing comment\n AND b = 2",
+    "INSERT INTO Commands VALUES (999999, \"echo 'test insert'\", \"echo\", \"bash\", 0, \"2025-12-01T12:00:00.000Z\", \"FALSE\", \"/home/test\", 1000, \"testuser\", \"test-host\", 1)",
+    "DELETE FROM Commands WHERE command_id = 999999",
+    "DESCRIBE Commands",
+    "UPDATE Commands",
+    "",
+    "   ",
+    "SELECT",
+    "SELECT * FROM",
+    "SELECT * FROM c WHERE",
+    "SELECT *, a FROM c",
+    "SELECT a b FROM c",
+    "SELECT * FROM c WHERE a > = 5",
+    "SELECT * FROM c WHERE a >= 5 AND b <= 6 AND c != 7 AND d < 8 AND e > 9",
+    "SELECT * FROM c WHERE a=1 AND(b=2)",
+    "SELECT * FROM c WHERE risk_level=5;SELECT 1",
+    "SELECT * FROM c WHERE name = \"semi;colon\"",
+    "SELECT * FROM c WHERE a = @ 5",
+    "SELECT * FROM c WHERE _x9 = 5 AND y_ = 'z'",
+]
+
+
+def make_edge_csv(path):
+    long_raw = "x" * 700 + "," + "y" * 600          # physical line > 1023 bytes -> split rows
+    lines = [
+        HEADER,
+        '1,"echo ""hi"", there",echo,bash,0,2025-01-01T00:00:00.000Z,true,/home/a,1001,alice,host-1,3',
+        "2,plain,ls,zsh,1,ts,FALSE,/tmp,1002,bob,host-2,1",
+        "3,,,,,,,,,,,",
+        "4,short",
+        '5,"quoted"tail,cat,sh,-1,ts,1,/,  -5 ,carol,h,+2',
+        "",
+        "6,cmd,base,bash,0,ts,True,/x,1003,dave,host,2\r",
+        "7,cmd,base,12345678901234567890,65,ts,TRUE,/x,1003,dave,host,2",      # shell_type fills all 20 bytes
+        "8,cmd,base,bash,0,123456789012345678901234567890,0,/x,1004,erin,host,4",  # timestamp fills 30 bytes, sudo false
+        "9,cmd,base,bash,0,123456789012345678901234567890,1,/x,1004,erin,host,4",  # ... sudo true (byte 0x01 follows)
+        "18446744073709551615,max,base,fish,130,ts,false,/m,2147483647,u,h,5",
+        "18446744073709551616,sat,base,fish,126,ts,false,/m,-2147483648,u,h,5",
+        "-1,neg,base,fish,127,ts,false,/m,1005,u,h,5",
+        "abc,nan,base,fish,2,ts,false,/m,12abc,u,h,x",
+        "10,dup,base,bash,0,ts,false,/d,1001,alice,host-1,3",
+        "10,dup,base,bash,0,ts,false,/d,1001,alice,host-1,3",
+        "10,dup2,base,bash,0,ts,true,/d,1001,alice,host-1,1",
+        f"11,{long_raw},base,bash,0,ts,false,/l,1006,long,host,2",
+        '12,"multi, comma, field","b,c",zsh,0,ts,false,"/w,d",1007,"na,me","ho,st",1',
+        "13,trailing,comma,bash,0,ts,false,/t,1008,tc,host,2,extra,fields",
+        " 14, lead space, ls ,bash, 0,ts, true,/s,1009,sp,host, 3",
+        "15,noeol,base,bash,0,ts,false,/n,1010,ne,host,1",           # file ends without newline
+    ]
+    data = "\n".join(lines)
+    path.write_bytes(data.encode("latin-1"))
+
+
+EDGE_SELECTS = [
+    ("E_all", "*", None),
+    ("E_risk3", "*", "risk_level = 3"),
+    ("E_shell20", "command_id, shell_type, exit_code", 'shell_type = "12345678901234567890"'),
+    ("E_shell20A", "command_id, shell_type", 'shell_type = "12345678901234567890A"'),
+    ("E_ts30", "command_id, timestamp, sudo_used", 'timestamp = "123456789012345678901234567890"'),
+    ("E_ts30_1", "command_id, timestamp, sudo_used", 'timestamp > "123456789012345678901234567890"'),
+    ("E_cid_max", "command_id, raw_command", "command_id = 18446744073709551615"),
+    ("E_cid0", "command_id, raw_command", "command_id = 0"),
+    ("E_uid_neg", "command_id, user_id", "user_id < 0"),
+    ("E_uid_max", "command_id, user_id", "user_id >= 2147483647"),
+    ("E_dup", "command_id, raw_command", "command_id = 10"),
+    ("E_empty_str", "command_id", 'raw_command = ""'),
+    ("E_sudo", "command_id, sudo_used", "sudo_used = TRUE"),
+    ("E_comma", "*", 'user_name = "na,me"'),
+    ("E_quote", "command_id, raw_command", "command_id = 1"),
+    ("E_lead", "command_id, raw_command, base_command, risk_level", 'base_command = " ls "'),
+]
+
+
+def sha_rows(rows):
+    h = hashlib.sha256()
+    for r in rows:
+        for c in r:
+            h.update(c.encode("latin-1"))
+            h.update(b"\x1f")
+        h.update(b"\x1e")
+    return h.hexdigest()
+
+
+def compose(select_list, where):
+    sql = f"SELECT {select_list} FROM Commands"
+    if where:
+        sql += f" WHERE {where}"
+    return sql
+
+
+def parse_with_ref(ref, sql):
+    text = q.call_text(ref.refh_parse, sql.encode("latin-1"))
+    head, wd = text.split(q.RS, 1)
+    return head, q.parse_where_dump(wd)
+
+
+def main():
+    ref = q.load_ref()
+    if ref is None:
+        sys.exit("oracle/_ref/libqpeseq_ref.so missing: run `make -C oracle` in the authoring container")
+    q.build_oracle()
+
+    csv2k = HERE / "commands_2k.csv"
+    if not csv2k.exists():
+        subprocess.run([sys.executable, str(REF_GEN), "2000", str(csv2k)], check=True)
+    edge = HERE / "edge_cases.csv"
+    make_edge_csv(edge)
+
+    # ---- parse golden -------------------------------------------------
+    parse_out = []
+    all_sql = list(PARSE_CASES) + [compose(s, w) for _, s, w in SELECT_CASES]
+    for sql in all_sql:
+        toks = q.call_text(ref.refh_tokens, sql.encode("latin-1"))
+        parsed = q.call_text(ref.refh_parse, sql.encode("latin-1"))
+        parse_out.append({"sql": sql, "tokens": toks, "parse": parsed})
+    (HERE / "parse_golden.json").write_text(json.dumps(parse_out, indent=0))
+
+    # ---- records golden -----------------------------------------------
+    rec_out = {}
+    for path, limit in ((edge, None), (csv2k, 8)):
+        eng = q.RefEngine(path, [])
+        n = eng.n if limit is None else min(limit, eng.n)
+        blob = b"".join(bytes(eng.record(i)) for i in range(n))
+        rec_out[path.name] = {"num_records": eng.n, "dumped": n,
+                              "zlib_b64": base64.b64encode(zlib.compress(blob, 9)).decode()}
+        eng.close()
+    (HERE / "records_golden.json").write_text(json.dumps(rec_out, indent=0))
+
+    # ---- index order golden -------------------------------------------
+    idx_attrs = [("command_id", 0), ("user_id", 1), ("risk_level", 1), ("exit_code", 1), ("sudo_used", 3),
+                 ("shell_type", 2), ("user_name", 2)]
+    idx_out = {}
+    for path in (csv2k, edge):
+        eng = q.RefEngine(path, idx_attrs)
+        idx_out[path.name] = {a: eng.index_order(i) for i, (a, _) in enumerate(idx_attrs)}
+        eng.close()
+    (HERE / "index_order_golden.json").write_text(json.dumps(idx_out, separators=(",", ":")))
+
+    # ---- select golden -------------------------------------------------
+    sel_out = []
+
+    def run_cases(path, cases, configs_for, ids_from_command_id):
+        engines = {}
+        oracles = {}
+        for name, sel, where in cases:
+            for cfg in configs_for(name):
+                if cfg not in engines:
+                    engines[cfg] = q.RefEngine(path, INDEX_CONFIGS[cfg])
+                    oracles[cfg] = q.OracleTable(path, INDEX_CONFIGS[cfg])
+                eng, orc = engines[cfg], oracles[cfg]
+                sql = compose(sel, where)
+                head, chain = parse_with_ref(ref, sql)
+                o_ids, o_count, cand = orc.select_ids(chain)
+                case = {"name": name, "csv": path.name, "indexes": cfg, "sql": sql,
+                        "where": q.chain_to_jsonable(chain), "candidates": cand}
+                cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]
+                if cand > eng.n:
+                    # would overflow the reference's candidate buffer: never run it there
+                    case.update(pinned=False, num_records=o_count, ids=o_ids,
+                                rows_sha256=sha_rows(orc.project(o_ids, cols)))
+                    sel_out.append(case)
+                    continue
+                res = eng.select(sql)
+                case.update(pinned=True, num_records=res["numRecords"], columns=res["columns"],
+                            rows_sha256=sha_rows(res["rows"]), first_rows=res["rows"][:3])
+                if ids_from_command_id:
+                    r2 = eng.select(compose("command_id", where))
+                    case["ids"] = [int(r[0]) for r in r2["rows"]]
+                sel_out.append(case)
+        for e in engines.values():
+            e.close()
+
+    run_cases(csv2k, SELECT_CASES, lambda n: CASE_CONFIGS + EXTRA_CONFIGS.get(n, []), True)
+    run_cases(edge, EDGE_SELECTS, lambda n: ["none", "default"], False)
+    (HERE / "select_golden.json").write_text(json.dumps(sel_out, separators=(",", ":")))
+
+    # ---- printTable golden ----------------------------------------------
+    prt = []
+    eng = q.RefEngine(csv2k, q.DEFAULT_INDEXES)
+    for name, limit in (("S1", 20), ("S4", 20), ("S7", 5), ("T_proj", 3), ("W_none_match", 20), ("A_cid_lt", 0)):
+        sel, where = next((s, w) for n_, s, w in SELECT_CASES if n_ == name)
+        sql = compose(sel, where)
+        with tempfile.NamedTemporaryFile(suffix=".txt") as tf:
+            rc = ref.refh_print(eng.h, sql.encode(), limit, tf.name.encode())
+            assert rc == 0
+            prt.append({"name": name, "sql": sql, "limit": limit, "indexes": "default",
+                        "text": pathlib.Path(tf.name).read_text(encoding="latin-1")})
+    eng.close()
+    (HERE / "print_golden.json").write_text(json.dumps(prt, indent=0))
+
+    unpinned = [c["name"] + "/" + c["indexes"] for c in sel_out if not c["pinned"]]
+    print(f"select cases: {len(sel_out)} ({len(unpinned)} not sent to the reference: {unpinned})")
+    print(f"parse cases: {len(parse_out)}")
+
+
+if __name__ == "__main__":
+    main()
