@@ -1,0 +1,353 @@
+#!/usr/bin/env python3
+"""bench.py -- rows/sec of the SELECT/WHERE scan-and-filter on the commands_* schema.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one execution of the hot path: the reference's Sample-1 query shape
+    WHERE sudo_used = FALSE AND user_name = "student1030"
+(the query QPESeq really runs through linearSearchRecords over every row, and the one
+BASELINE.md anchors on) over the rank's row-range shard of the seeded synthetic table,
+inputs resident in HBM, through the C-ABI (pqps_filter_scan).  With N > 1 the step
+also merges the matching row IDs of all shards on every rank (count all-gather +
+slot all-gather over RCCL + device compaction), pipelined on a second stream.
+Workload = BASELINE.json configs[1]: 100 M synthetic rows per GPU (weak scaling:
+N GPUs scan N x 100 M rows).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+PKG = ROOT / "parallel-query-processing-system_amd"
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+QUERIES = {
+    # name: (chain, SQL text as in the reference's sample-queries.txt where it exists)
+    "S1": ([("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")],
+           'sudo_used = FALSE AND user_name = "student1030"'),
+    "Q_A": ([("risk_level", ">", "3")], "risk_level > 3"),
+    "Q_B": ([("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")], "sudo_used = TRUE AND risk_level > 2"),
+    "Q_C": ([("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1500"), "OR", ("risk_level", "=", "5")],
+            "exit_code != 0 AND user_id >= 1500 OR risk_level = 5"),
+}
+
+
+def load_pkg():
+    spec = importlib.util.spec_from_file_location("pqps_amd", PKG / "__init__.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["pqps_amd"] = mod
+    spec.loader.exec_module(mod)
+    spec2 = importlib.util.spec_from_file_location("pqps_amd_merge", PKG / "merge.py")
+    mg = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(mg)
+    return mod, mg
+
+
+def cpu_baseline(pq, chain, sql, seed, log):
+    """QPESeq-equivalent CPU rate on this box's host cores, bounded sample (rank 0, N=1).
+
+    kind "reference": the reference's own linearSearchRecords (oracle/_ref, compiled
+    from its sources) over 1040-byte AoS records;  else kind "port": the oracle's
+    row-at-a-time evaluator over the same columns.  The OpenMP row-parallel port is
+    reported next to it (`omp`)."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    import qpelib as q
+
+    ncores = os.cpu_count() or 1
+    out = {}
+    n_col = 20_000_000
+    host = q.HostSynth(n_col, seed=seed)
+    t0 = time.perf_counter()
+    k1 = len(host.oracle_scan(chain, nthreads=1))
+    t_port = time.perf_counter() - t0
+    nth = min(ncores, 64)
+    t0 = time.perf_counter()
+    k2 = len(host.oracle_scan(chain, nthreads=nth))
+    t_omp = time.perf_counter() - t0
+    assert k1 == k2
+    port = {"value": n_col / t_port, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{n_col} synthetic rows (columnar), query {sql!r}, {k1} matches, oracle serial evaluator"}
+    omp = {"value": n_col / t_omp, "unit": "rows/s", "cores": nth, "kind": "port",
+           "sample": f"{n_col} rows, OpenMP row ranges x{nth}"}
+    log(f"cpu port: serial {port['value']/1e6:.1f} M rows/s, omp x{nth} {omp['value']/1e6:.1f} M rows/s")
+
+    ref = q.load_ref()
+    if ref is None:
+        port["omp"] = omp
+        return port
+    # the real reference over AoS records built from the same synthetic columns
+    n_aos = 8_000_000
+    rec_dt = np.dtype({"names": ["command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
+                                 "sudo_used", "working_directory", "user_id", "user_name", "host_name", "risk_level"],
+                       "formats": ["<u8", "S512", "S100", "S20", "<i4", "S30", "u1", "S200", "<i4", "S50", "S100", "<i4"],
+                       "offsets": [0, 8, 520, 620, 640, 644, 674, 675, 876, 880, 930, 1032], "itemsize": 1040})
+    recs = np.zeros(n_aos, dtype=rec_dt)
+    a = {k: v[:n_aos] for k, v in host.arr.items()}
+    recs["command_id"] = a["command_id"]
+    recs["exit_code"], recs["user_id"], recs["risk_level"] = a["exit_code"], a["user_id"], a["risk_level"]
+    recs["sudo_used"] = a["sudo_used"]
+    recs["shell_type"] = np.array(pq.SYNTH_SHELLS, dtype="S20")[a["shell_type"]]
+    recs["user_name"] = np.array(pq.SYNTH_USERS_DICT, dtype="S50")[a["user_name"]]
+    recs["host_name"] = np.array(pq.SYNTH_HOSTS, dtype="S100")[a["host_name"]]
+    recs["base_command"] = np.array(pq.SYNTH_BASES, dtype="S100")[a["base_command"]]
+    recs["raw_command"], recs["timestamp"], recs["working_directory"] = b"cmd", b"2025-01-01T00:00:00.000Z", b"/home/u"
+    ptrs = (recs.ctypes.data + np.arange(n_aos, dtype=np.uint64) * 1040).astype(np.uint64)
+    ref.linearSearchRecords.restype = C.c_void_p
+    ref.linearSearchRecords.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    wl = pq.WhereList(chain)
+    best = None
+    for _ in range(3):
+        cnt = C.c_int()
+        t0 = time.perf_counter()
+        res = ref.linearSearchRecords(ptrs.ctypes.data, n_aos, C.cast(wl.ptr, C.c_void_p), C.byref(cnt))
+        dt = time.perf_counter() - t0
+        libc.free(res)
+        best = dt if best is None else min(best, dt)
+    want = int(np.searchsorted(host.oracle_scan(chain), n_aos))
+    assert cnt.value == want, (cnt.value, want)
+    log(f"cpu reference (QPESeq linearSearchRecords): {n_aos / best / 1e6:.2f} M rows/s on 1 core")
+    return {"value": n_aos / best, "unit": "rows/s", "cores": 1, "kind": "reference",
+            "sample": f"{n_aos} AoS records (1040 B) of the same synthetic table, query {sql!r}, "
+                      f"reference linearSearchRecords compiled -O2, best of 3",
+            "port_serial": port, "port_omp": omp}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
+    ap.add_argument("--query", default="S1", choices=sorted(QUERIES))
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary queries / read probe")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+
+    pq, mg = load_pkg()
+    ctx = pq.Context(dev_index)
+    dev_name, cus, hbm = ctx.info()
+    compute = torch.cuda.current_stream()
+    sptr = compute.cuda_stream
+
+    chain, sql = QUERIES[args.query]
+    n_global = args.rows * world
+    start, count = mg.shard_rows(n_global, world, rank)
+    if start + count > 2**32:
+        sys.exit("row IDs are u32: rows * gpus must stay below 2^32")
+
+    # ---- table: this rank's row range, generated in place on the device -----------------
+    keep = []
+
+    def alloc(nbytes):
+        t = torch.empty(nbytes + 64, dtype=torch.uint8, device=device)
+        keep.append(t)
+        return t.data_ptr()
+
+    extras = [] if args.no_extras else [k for k in QUERIES if k != args.query]
+    needed = {leaf[0] for k in [args.query] + extras for leaf in _leaves(QUERIES[k][0])} & set(pq.COLUMNS)
+    t0 = time.perf_counter()
+    table = pq.SyntheticTable(ctx, count, seed=args.seed, row0=start, columns=sorted(needed), alloc=alloc, stream=sptr)
+    torch.cuda.synchronize()
+    log(f"{dev_name}, {cus} CUs: generated {count:,} rows x {sorted(needed)} in {time.perf_counter() - t0:.2f} s")
+
+    pred, cols, nc, bytes_per_row = table.bind(chain)
+    L = pq.lib()
+
+    # ---- result buffers (double-buffered for the merge pipeline) ---------------------------
+    # slot capacity from one calibration run of the same query (selectivity is a property of
+    # the data, identical on every step); +25 % head-room, overflow is checked after timing
+    cal_ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
+    cal_cnt = torch.zeros(1, dtype=torch.int64, device=device)
+    pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), cal_ids.data_ptr(), count,
+                                cal_cnt.data_ptr(), sptr), "calibration scan")
+    torch.cuda.synchronize()
+    local_matches = int(cal_cnt.item())
+    max_matches = local_matches
+    if world > 1:
+        mm = torch.tensor([local_matches], dtype=torch.int64, device=device)
+        dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+        max_matches = int(mm.item())
+    slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096
+    del cal_ids
+    mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq) for _ in range(2)]
+    comm = torch.cuda.Stream(device=device)
+    filt_done = [torch.cuda.Event() for _ in range(2)]
+    merge_done = [torch.cuda.Event() for _ in range(2)]
+
+    def step(k):
+        m = mergers[k & 1]
+        compute.wait_event(merge_done[k & 1])            # slot k&1 free again (no-op before first record)
+        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_local.data_ptr(), slot_cap,
+                                    m.count_local.data_ptr(), sptr), "pqps_filter_scan")
+        if world == 1:
+            return
+        filt_done[k & 1].record(compute)
+        with torch.cuda.stream(comm):
+            comm.wait_event(filt_done[k & 1])
+            m.merge(stream_ptr=comm.cuda_stream)
+            merge_done[k & 1].record(comm)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = ctx.kernel_time()
+    ctx.set_timing(False)
+    ctx.sync(sptr)                                       # also surfaces a look-back timeout
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- verify what the timed steps produced ------------------------------------------------
+    last = mergers[(args.steps - 1) & 1] if args.steps > 0 else mergers[0]
+    got_local = int(last.count_local.item())
+    assert got_local == local_matches, (got_local, local_matches)
+    total_matches = local_matches
+    if world > 1:
+        merged = last.result()
+        import numpy as np
+        assert len(merged) > 0 and bool(np.all(merged[1:] > merged[:-1])), "merged IDs are not strictly ascending"
+        tm = torch.tensor([local_matches], dtype=torch.int64, device=device)
+        dist.all_reduce(tm)
+        total_matches = int(tm.item())
+        assert len(merged) == total_matches, (len(merged), total_matches)
+
+    rows_per_s = n_global * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    avg_kernel_ms = kern_ms / max(launches, 1)
+    alg_bytes = count * bytes_per_row + 4 * local_matches          # n * sum w(c) + 4 * matches
+    achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "rows/sec SELECT-filter on commands_* schema",
+        "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: SELECT/WHERE scan-filter on the commands_* schema, {args.rows:,} synthetic rows per GPU",
+                   "query": sql, "rows_per_gpu": args.rows, "rows_total": n_global,
+                   "matches_total": total_matches, "selectivity": total_matches / n_global,
+                   "bytes_per_row": bytes_per_row,
+                   "parallelism": f"row-range shards x{world}" + (", RCCL count+ID all-gather merge on every rank" if world > 1 else ""),
+                   "device": dev_name},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "filter_kernel<MODE_IDS,false>", "avg_kernel_ms": avg_kernel_ms,
+                     "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    if rank == 0 and not args.no_extras:
+        result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+def _leaves(chain):
+    for x in chain[0::2]:
+        if isinstance(x, list):
+            yield from _leaves(x)
+        else:
+            yield x
+
+
+def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log):
+    """Untimed-by-the-contract side measurements: other query shapes (kernel-only GB/s),
+    COUNT(*) mode and the plain streaming-read ceiling of this box."""
+    out = {}
+    ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
+    cnt = torch.zeros(2, dtype=torch.int64, device=device)
+    reps = 20
+    for name in names:
+        chain, sql = QUERIES[name]
+        pred, cols, nc, bpr = table.bind(chain)
+        for mode in ("ids", "count"):
+            def run():
+                if mode == "ids":
+                    pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), ids.data_ptr(), count, cnt.data_ptr(), sptr))
+                else:
+                    pq.check(L.pqps_filter_count(ctx.h, cols, nc, count, C.byref(pred), cnt.data_ptr(), sptr))
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            ctx.set_timing(True)
+            for _ in range(reps):
+                run()
+            ms, k = ctx.kernel_time()
+            ctx.set_timing(False)
+            matches = int(cnt[0].item())
+            byts = count * bpr + (4 * matches if mode == "ids" else 8)
+            out[f"{name}_{mode}"] = {"query": sql, "rows_per_s": count / (ms / k * 1e-3), "matches": matches,
+                                      "bytes_per_row": bpr, "GBps": byts / (ms / k * 1e-3) / 1e9,
+                                      "frac_of_8TBps": byts / (ms / k * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_kernel_ms": ms / k}
+            log(f"{name:>4} {mode:>5}: {out[f'{name}_{mode}']['rows_per_s']/1e9:.1f} G rows/s, "
+                f"{out[f'{name}_{mode}']['GBps']:.0f} GB/s ({100*out[f'{name}_{mode}']['frac_of_8TBps']:.1f} % of 8 TB/s)")
+    # plain streaming-read ceiling (uint4 load + add), for context next to the 8 TB/s spec
+    nbytes = 2 << 30
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    buf.zero_()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        pq.check(L.pqps_read_probe(ctx.h, buf.data_ptr(), nbytes, cnt.data_ptr(), sptr))
+    ev0.record()
+    for _ in range(10):
+        pq.check(L.pqps_read_probe(ctx.h, buf.data_ptr(), nbytes, cnt.data_ptr(), sptr))
+    ev1.record()
+    torch.cuda.synchronize()
+    out["read_probe_GBps"] = nbytes * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    log(f"streaming read probe: {out['read_probe_GBps']:.0f} GB/s")
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -67,9 +67,20 @@ FieldType mapAttributeTypeHIP(int attributeType);
 /* Builds the device index for one attribute and appends it to the engine. */
 bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeType);
 
-/* rows -> columns -> device.  Creates engine->record_block. */
+/* rows -> columns -> device.  Replaces engine->record_block (the row block
+ * returned by getAllRecordsFromFileHIP) by the struct hipTable that owns it. */
 bool buildDeviceTableHIP(struct engineS *engine);
+/* Re-creates columns, dictionaries and indexes from engine->all_records
+ * (after INSERT / DELETE changed the host rows). */
+void rebuildDeviceTableHIP(struct engineS *engine);
 void destroyDeviceTableHIP(struct engineS *engine);
+
+/* Lower-level pieces (also used for ad-hoc tables over caller-supplied rows,
+ * see linearSearchRecords / evaluateWhereClause in executeEngine-hip.c). */
+struct hipSchema;
+struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n);
+void hipTableFree(struct hipTable *t, int n_indexes);
+void hipSchemaOfTable(const struct hipTable *t, struct hipSchema *s);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,12 @@ int  pqps_ctx_create(int device, pqps_ctx **out);
 void pqps_ctx_destroy(pqps_ctx *ctx);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
+/* Per-launch HIP-event timing of the filter kernel itself (events recorded on
+ * the launch stream right around the kernel, up to 4096 launches per reset).
+ * pqps_ctx_kernel_time waits for the recorded launches, returns the sum of
+ * their durations and their number, and resets the recorder. */
+int  pqps_ctx_set_timing(pqps_ctx *ctx, int enable);
+int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *total_ms, int *launches);
 /* Fills name (<=63 chars), CU count and total HBM bytes of the ctx device. */
 int  pqps_device_info(pqps_ctx *ctx, char *name64, int *compute_units, uint64_t *hbm_bytes);
 
@@ -149,6 +155,17 @@ int pqps_index_build(pqps_ctx *ctx, const pqps_column *col, uint64_t n_rows, int
 int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int key_kind,
                      uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
                      uint64_t *range, void *stream);
+
+/* Tail of the all-gatherv merge.  `segments` holds `world` equal-size slots of
+ * `segment_capacity` u32 (what an equal-size RCCL all-gather delivered), slot r
+ * carrying counts[r] ascending IDs; writes their rank-order concatenation to
+ * `merged` -- the recvCounts / displs layout of MPI_Allgatherv
+ * (engine/mpi/executeEngine-mpi.c:753-765) -- and, if `totals` != NULL,
+ * totals[0] = IDs merged, totals[1] = sum of counts (larger => a slot overflowed).
+ * Everything is device resident: no host round trip. */
+int pqps_merge_segments(pqps_ctx *ctx, const uint32_t *segments, const uint64_t *counts, uint32_t world,
+                        uint64_t segment_capacity, uint32_t *merged, uint64_t merged_capacity,
+                        uint64_t *totals, void *stream);
 
 /* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */
 void pqps_partition(uint64_t n_rows, int world, int rank, uint64_t *start, uint64_t *count);

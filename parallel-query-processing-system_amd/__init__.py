@@ -1,0 +1,497 @@
+"""ctypes binding of the MI355X SELECT/WHERE backend (libpqps_hip.so).
+
+The product is C: `csrc/pqps_hip.hip` (kernels + C-ABI shim, include/pqps_hip.h)
+and the C11 engine under `engine/hip/` + `host/` (include/executeEngine-hip.h).
+This module only mirrors those headers for Python callers (tests, bench.py);
+it contains no compute and no fallback: if the shared library is missing or
+no GPU is visible, calls fail loudly.
+
+The directory name contains '-', so import it with::
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location(
+        "pqps_amd", "<repo>/parallel-query-processing-system_amd/__init__.py")
+    pqps_amd = importlib.util.module_from_spec(spec); sys.modules["pqps_amd"] = pqps_amd
+    spec.loader.exec_module(pqps_amd)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+PKG_DIR = pathlib.Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libpqps_hip.so"
+
+MAX_COLUMNS = 12
+MAX_LEAVES = 32
+TT_LEAVES = 6
+TILE_ROWS = 4096
+ACCEPT, REJECT = 0xFE, 0xFF
+SYNTH_USERS = 2000
+
+COLUMNS = ["command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
+           "sudo_used", "working_directory", "user_id", "user_name", "host_name", "risk_level"]
+COL = {name: i for i, name in enumerate(COLUMNS)}
+KIND_U64, KIND_I32, KIND_BOOL, KIND_DICT = 0, 1, 2, 3
+COLUMN_KIND = [KIND_U64, KIND_DICT, KIND_DICT, KIND_DICT, KIND_I32, KIND_DICT,
+               KIND_BOOL, KIND_DICT, KIND_I32, KIND_DICT, KIND_DICT, KIND_I32]
+FIELD_UINT64, FIELD_INT, FIELD_STRING, FIELD_BOOL = 0, 1, 2, 3
+DEFAULT_INDEXES = [("command_id", 0), ("user_id", 1), ("risk_level", 1), ("exit_code", 1), ("sudo_used", 3)]
+
+
+# ---- include/logType.h, include/executeEngine-serial.h ---------------------
+class Record(C.Structure):
+    _fields_ = [
+        ("command_id", C.c_ulonglong),
+        ("raw_command", C.c_char * 512),
+        ("base_command", C.c_char * 100),
+        ("shell_type", C.c_char * 20),
+        ("exit_code", C.c_int),
+        ("timestamp", C.c_char * 30),
+        ("sudo_used", C.c_bool),
+        ("working_directory", C.c_char * 200),
+        ("user_id", C.c_int),
+        ("user_name", C.c_char * 50),
+        ("host_name", C.c_char * 100),
+        ("risk_level", C.c_int),
+    ]
+
+
+class WhereClause(C.Structure):
+    pass
+
+
+WhereClause._fields_ = [
+    ("attribute", C.c_char_p),
+    ("operator", C.c_char_p),
+    ("value", C.c_char_p),
+    ("value_type", C.c_int),
+    ("next", C.POINTER(WhereClause)),
+    ("logical_op", C.c_char_p),
+    ("sub", C.POINTER(WhereClause)),
+]
+
+
+class ResultSet(C.Structure):
+    _fields_ = [
+        ("numRecords", C.c_int),
+        ("numColumns", C.c_int),
+        ("columnNames", C.POINTER(C.c_char_p)),
+        ("columnTypes", C.POINTER(C.c_int)),
+        ("data", C.POINTER(C.POINTER(C.c_char_p))),
+        ("queryTime", C.c_double),
+        ("success", C.c_bool),
+    ]
+
+
+class EngineS(C.Structure):
+    _fields_ = [
+        ("tableName", C.c_char_p),
+        ("bplus_tree_roots", C.c_void_p),
+        ("num_indexes", C.c_int),
+        ("indexed_attributes", C.POINTER(C.c_char_p)),
+        ("attribute_types", C.POINTER(C.c_int)),
+        ("all_records", C.POINTER(C.POINTER(Record))),
+        ("num_records", C.c_int),
+        ("datafile", C.c_char_p),
+        ("record_block", C.c_void_p),
+    ]
+
+
+# ---- include/pqps_hip.h -------------------------------------------------------
+class Column(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Leaf(C.Structure):
+    _fields_ = [("column", C.c_uint32), ("negate", C.c_uint32), ("lo", C.c_uint64), ("span", C.c_uint64)]
+
+
+class Predicate(C.Structure):
+    _fields_ = [
+        ("n_leaves", C.c_uint32),
+        ("n_columns", C.c_uint32),
+        ("truth", C.c_uint64),
+        ("leaf", Leaf * MAX_LEAVES),
+        ("on_true", C.c_uint8 * MAX_LEAVES),
+        ("on_false", C.c_uint8 * MAX_LEAVES),
+        ("order", C.c_uint8 * MAX_LEAVES),
+    ]
+
+
+class SynthCols(C.Structure):
+    _fields_ = [
+        ("command_id", C.c_void_p), ("exit_code", C.c_void_p), ("user_id", C.c_void_p),
+        ("risk_level", C.c_void_p), ("sudo_used", C.c_void_p), ("shell_code", C.c_void_p),
+        ("user_code", C.c_void_p), ("host_code", C.c_void_p), ("base_code", C.c_void_p),
+    ]
+
+
+# ---- include/hipPredicate.h ----------------------------------------------------
+class ColumnInfo(C.Structure):
+    _fields_ = [("present", C.c_int), ("kind", C.c_int), ("width", C.c_uint32),
+                ("dict_count", C.c_int), ("dict", C.POINTER(C.c_char_p))]
+
+
+class Schema(C.Structure):
+    _fields_ = [("col", ColumnInfo * MAX_COLUMNS)]
+
+
+assert C.sizeof(Record) == 1040 and C.sizeof(WhereClause) == 56
+assert C.sizeof(ResultSet) == 48 and C.sizeof(EngineS) == 72
+
+
+class PqpsError(RuntimeError):
+    pass
+
+
+# ---- WHERE lists ------------------------------------------------------------------
+# A python "chain" alternates items and "AND"/"OR"; an item is (attr, op, value[, value_type])
+# or a nested chain (list):
+#   [("sudo_used","=","TRUE"), "OR", [("risk_level","=","5"), "AND", ("shell_type","=","bash")]]
+class WhereList:
+    """Owns the ctypes nodes of one whereClauseS list."""
+
+    def __init__(self, chain):
+        self._keep = []
+        self.head = self._build(chain)
+
+    def _build(self, chain):
+        if not chain:
+            return None
+        items, ops = chain[0::2], chain[1::2]
+        nodes = []
+        for it in items:
+            n = WhereClause()
+            if isinstance(it, list):
+                sub = self._build(it)
+                n.sub = C.pointer(sub) if sub is not None else None
+            else:
+                a, o, v = it[:3]
+                n.attribute = a.encode() if a is not None else None
+                n.operator = o.encode() if o is not None else None
+                n.value = v.encode("latin-1") if v is not None else None
+                n.value_type = it[3] if len(it) > 3 else 0
+            self._keep.append(n)
+            nodes.append(n)
+        for i, n in enumerate(nodes[:-1]):
+            n.next = C.pointer(nodes[i + 1])
+            n.logical_op = ops[i].encode() if ops[i] is not None else None
+        return nodes[0]
+
+    @property
+    def ptr(self):
+        return C.byref(self.head) if self.head is not None else None
+
+
+# ---- library --------------------------------------------------------------------------
+_lib = None
+
+
+def build_library():
+    """`make` in the package directory (hipcc --offload-arch=gfx950 + gcc)."""
+    subprocess.run(["make", "-s", "-C", str(PKG_DIR)], check=True)
+
+
+def lib():
+    """The product shared object.  Never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PqpsError(f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    W = C.POINTER(WhereClause)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.pqps_last_error.restype = C.c_char_p
+    L.pqps_device_count.restype = C.c_int
+    L.pqps_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.pqps_ctx_destroy.argtypes = [vp]
+    L.pqps_ctx_destroy.restype = None
+    L.pqps_ctx_sync.argtypes = [vp, vp]
+    L.pqps_ctx_set_timing.argtypes = [vp, C.c_int]
+    L.pqps_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pqps_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(u64)]
+    L.pqps_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.pqps_free.argtypes = [vp, vp]
+    L.pqps_memset.argtypes = [vp, vp, C.c_int, C.c_size_t, vp]
+    L.pqps_upload.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.pqps_download.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    L.pqps_filter_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
+    L.pqps_filter_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
+    L.pqps_filter_flags.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp, vp]
+    L.pqps_filter_gather.argtypes = [vp, C.POINTER(Column), u32, vp, vp, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
+    L.pqps_index_build.argtypes = [vp, C.POINTER(Column), u64, C.c_int, vp, vp, vp]
+    L.pqps_index_probe.argtypes = [vp, vp, u32, C.c_int, u64, u64, u64, vp, vp]
+    L.pqps_partition.argtypes = [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+    L.pqps_partition.restype = None
+    L.pqps_synth_user_tables.argtypes = [u64, vp, vp]
+    L.pqps_synth_user_tables.restype = None
+    L.pqps_synth_generate.argtypes = [vp, u64, u64, u64, vp, vp, C.POINTER(SynthCols), vp]
+    L.pqps_synth_generate_host.argtypes = [u64, u64, u64, vp, vp, C.POINTER(SynthCols)]
+    L.pqps_synth_generate_host.restype = None
+    L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
+    L.pqps_merge_segments.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
+    L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    L.hipColumnId.argtypes = [C.c_char_p]
+    for name in ("hipDumpTokens", "hipDumpParse"):
+        f = getattr(L, name)
+        f.restype = C.c_longlong
+        f.argtypes = [C.c_char_p, C.c_char_p, C.c_longlong]
+    # engine API (include/executeEngine-hip.h)
+    E = C.POINTER(EngineS)
+    L.initializeEngineHIP.restype = E
+    L.initializeEngineHIP.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_char_p, C.c_char_p]
+    L.destroyEngineHIP.argtypes = [E]
+    L.destroyEngineHIP.restype = None
+    L.executeQuerySelectHIP.restype = C.POINTER(ResultSet)
+    L.executeQuerySelectHIP.argtypes = [E, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, W]
+    L.executeQuerySelectIdsHIP.restype = C.c_longlong
+    L.executeQuerySelectIdsHIP.argtypes = [E, W, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_double)]
+    L.executeQueryCountHIP.restype = C.c_longlong
+    L.executeQueryCountHIP.argtypes = [E, W]
+    L.executeQueryDeleteHIP.restype = C.POINTER(ResultSet)
+    L.executeQueryDeleteHIP.argtypes = [E, C.c_char_p, W]
+    L.executeQueryInsertHIP.restype = C.c_bool
+    L.executeQueryInsertHIP.argtypes = [E, C.c_char_p, C.POINTER(Record)]
+    L.addAttributeIndexHIP.restype = C.c_bool
+    L.addAttributeIndexHIP.argtypes = [E, C.c_char_p, C.c_char_p, C.c_int]
+    L.freeResultSet.argtypes = [C.POINTER(ResultSet)]
+    L.freeResultSet.restype = None
+    L.evaluateWhereClause.restype = C.c_bool
+    L.evaluateWhereClause.argtypes = [C.POINTER(Record), W]
+    L.linearSearchRecords.restype = C.POINTER(C.POINTER(Record))
+    L.linearSearchRecords.argtypes = [C.POINTER(C.POINTER(Record)), C.c_int, W, C.POINTER(C.c_int)]
+    L.isAttributeIndexed.argtypes = [E, C.c_char_p]
+    L.printTable.argtypes = [vp, C.POINTER(ResultSet), C.c_int]
+    L.printTable.restype = None
+    L.run_test_query.argtypes = [E, C.c_char_p, C.c_int]
+    L.run_test_query.restype = None
+    L.free.argtypes = [vp]
+    L.free.restype = None
+    _lib = L
+    return L
+
+
+def check(rc, what="pqps call"):
+    if rc != 0:
+        raise PqpsError(f"{what} failed ({rc}): {lib().pqps_last_error().decode()}")
+
+
+# ---- predicate compile --------------------------------------------------------------------
+class SchemaSpec:
+    """Python-side description of which columns exist (width, dictionary)."""
+
+    def __init__(self):
+        self.schema = Schema()
+        self._keep = []
+        for i, kind in enumerate(COLUMN_KIND):
+            self.schema.col[i].kind = kind
+
+    def set_numeric(self, name, width):
+        c = self.schema.col[COL[name]]
+        c.present, c.width = 1, width
+        return self
+
+    def set_dict(self, name, width, values):
+        """values: list of bytes, ascending in strcmp (= bytes) order."""
+        arr = (C.c_char_p * max(1, len(values)))()
+        for i, v in enumerate(values):
+            arr[i] = v
+        self._keep.append(arr)
+        c = self.schema.col[COL[name]]
+        c.present, c.width, c.dict_count, c.dict = 1, width, len(values), arr
+        return self
+
+
+def compile_where(spec: SchemaSpec, chain):
+    """-> (Predicate, [column id per slot]).  Raises PqpsError when not expressible."""
+    wl = WhereList(chain)
+    pred = Predicate()
+    ids = (C.c_int * MAX_COLUMNS)()
+    err = C.create_string_buffer(200)
+    rc = lib().hipCompileWhere(C.byref(spec.schema), wl.ptr, C.byref(pred), ids, err, 200)
+    if rc != 0:
+        raise PqpsError("hipCompileWhere: " + err.value.decode())
+    return pred, list(ids[:pred.n_columns])
+
+
+# ---- device objects ----------------------------------------------------------------------------
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        check(lib().pqps_ctx_create(device, C.byref(self.h)), "pqps_ctx_create")
+
+    def info(self):
+        name = C.create_string_buffer(64)
+        cus, hbm = C.c_int(), C.c_uint64()
+        check(lib().pqps_device_info(self.h, name, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().pqps_malloc(self.h, nbytes, C.byref(p)), "pqps_malloc")
+        return p.value
+
+    def free(self, p):
+        check(lib().pqps_free(self.h, p))
+
+    def upload(self, dptr, buf, nbytes, stream=None):
+        check(lib().pqps_upload(self.h, dptr, buf, nbytes, stream), "pqps_upload")
+
+    def download(self, host, dptr, nbytes, stream=None):
+        check(lib().pqps_download(self.h, host, dptr, nbytes, stream), "pqps_download")
+
+    def memset(self, dptr, value, nbytes, stream=None):
+        check(lib().pqps_memset(self.h, dptr, value, nbytes, stream))
+
+    def sync(self, stream=None):
+        check(lib().pqps_ctx_sync(self.h, stream), "pqps_ctx_sync")
+
+    def set_timing(self, on=True):
+        check(lib().pqps_ctx_set_timing(self.h, 1 if on else 0))
+
+    def kernel_time(self):
+        """-> (sum of filter-kernel durations in ms, number of launches) since the last call."""
+        ms, k = C.c_double(), C.c_int()
+        check(lib().pqps_ctx_kernel_time(self.h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    def close(self):
+        if self.h:
+            lib().pqps_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def column_array(pairs):
+    """[(device_ptr, width), ...] -> ctypes array of pqps_column."""
+    arr = (Column * max(1, len(pairs)))()
+    for i, (p, w) in enumerate(pairs):
+        arr[i].data, arr[i].width = p, w
+    return arr
+
+
+SYNTH_SHELLS = [b"bash", b"fish", b"sh", b"zsh"]
+SYNTH_HOSTS = sorted([b"labpc-01", b"labpc-02", b"labpc-03", b"labpc-04", b"labpc-05", b"labpc-06",
+                      b"labpc-07", b"labpc-08", b"labpc-09", b"labpc-10", b"vm-ubuntu-01", b"vm-ubuntu-02",
+                      b"cs-lab-01", b"cs-lab-02", b"personal-laptop", b"remote-ssh-01"])
+SYNTH_USERS_DICT = [b"student%d" % (1000 + i) for i in range(SYNTH_USERS)]
+SYNTH_BASES = sorted(b"cmd%03d" % i for i in range(111))
+# (record column, SynthCols field, bytes per row)
+SYNTH_LAYOUT = [("command_id", "command_id", 8), ("exit_code", "exit_code", 4), ("user_id", "user_id", 4),
+                ("risk_level", "risk_level", 4), ("sudo_used", "sudo_used", 1), ("shell_type", "shell_code", 1),
+                ("user_name", "user_code", 2), ("host_name", "host_code", 1), ("base_command", "base_code", 1)]
+
+
+def synth_schema():
+    s = SchemaSpec()
+    for name, w in (("command_id", 8), ("exit_code", 4), ("user_id", 4), ("risk_level", 4), ("sudo_used", 1)):
+        s.set_numeric(name, w)
+    s.set_dict("shell_type", 1, SYNTH_SHELLS)
+    s.set_dict("user_name", 2, SYNTH_USERS_DICT)
+    s.set_dict("host_name", 1, SYNTH_HOSTS)
+    s.set_dict("base_command", 1, SYNTH_BASES)
+    return s
+
+
+def synth_user_tables(seed):
+    cdf = (C.c_uint32 * SYNTH_USERS)()
+    shell = (C.c_uint8 * SYNTH_USERS)()
+    lib().pqps_synth_user_tables(seed, cdf, shell)
+    return cdf, shell
+
+
+class SyntheticTable:
+    """Rows [row0, row0+n) of the seeded commands_* table, resident on the device.
+
+    alloc(nbytes) -> device pointer lets the caller own the memory (bench.py passes a
+    torch allocator); default is pqps_malloc.  Only `columns` are materialised."""
+
+    def __init__(self, ctx: Context, n_rows, seed=0x5EED, row0=0, columns=None, alloc=None, stream=None):
+        self.ctx, self.n, self.seed, self.row0 = ctx, n_rows, seed, row0
+        self.schema = synth_schema()
+        wanted = set(columns) if columns is not None else {c for c, _, _ in SYNTH_LAYOUT}
+        cap = (n_rows + TILE_ROWS - 1) // TILE_ROWS * TILE_ROWS + TILE_ROWS
+        self._own = alloc is None
+        alloc = alloc or ctx.malloc
+        self.ptr, self.width = {}, {}
+        sc = SynthCols()
+        for name, field, w in SYNTH_LAYOUT:
+            if name not in wanted:
+                self.schema.schema.col[COL[name]].present = 0
+                continue
+            p = alloc(cap * w)
+            self.ptr[name], self.width[name] = p, w
+            setattr(sc, field, p)
+        for name in COLUMNS:
+            if name not in self.ptr:
+                self.schema.schema.col[COL[name]].present = 0
+        cdf, shell = synth_user_tables(seed)
+        self._cdf_dev, self._shell_dev = ctx.malloc(4 * SYNTH_USERS), ctx.malloc(SYNTH_USERS)
+        ctx.upload(self._cdf_dev, cdf, 4 * SYNTH_USERS)
+        ctx.upload(self._shell_dev, shell, SYNTH_USERS)
+        check(lib().pqps_synth_generate(ctx.h, seed, row0, n_rows, self._cdf_dev, self._shell_dev, C.byref(sc), stream),
+              "pqps_synth_generate")
+        ctx.sync(stream)
+
+    def bind(self, chain):
+        """-> (Predicate, pqps_column array, n_cols, algorithmic bytes per row)."""
+        pred, ids = compile_where(self.schema, chain)
+        cols = column_array([(self.ptr[COLUMNS[i]], self.width[COLUMNS[i]]) for i in ids])
+        return pred, cols, len(ids), sum(self.width[COLUMNS[i]] for i in ids)
+
+    def free(self):
+        if self._own:
+            for p in self.ptr.values():
+                self.ctx.free(p)
+        self.ctx.free(self._cdf_dev)
+        self.ctx.free(self._shell_dev)
+        self.ptr = {}
+
+
+class HipEngine:
+    """initializeEngineHIP / executeQuerySelectHIP / destroyEngineHIP from Python."""
+
+    def __init__(self, csv_path, indexes=()):
+        L = lib()
+        names = (C.c_char_p * max(1, len(indexes)))(*[a.encode() for a, _ in indexes])
+        types = (C.c_int * max(1, len(indexes)))(*[t for _, t in indexes])
+        self.e = L.initializeEngineHIP(len(indexes), names, types, str(csv_path).encode(), b"commands")
+        self.n = self.e.contents.num_records
+
+    def select_ids(self, chain):
+        wl = WhereList(chain)
+        ids = C.POINTER(C.c_uint)()
+        qt = C.c_double()
+        k = lib().executeQuerySelectIdsHIP(self.e, wl.ptr, C.byref(ids), C.byref(qt))
+        if k < 0:
+            raise PqpsError("executeQuerySelectIdsHIP failed")
+        out = list(ids[:k])
+        lib().free(ids)
+        return out
+
+    def count(self, chain):
+        wl = WhereList(chain)
+        return lib().executeQueryCountHIP(self.e, wl.ptr)
+
+    def select(self, columns, chain):
+        wl = WhereList(chain)
+        items = (C.c_char_p * max(1, len(columns or [])))(*[c.encode() for c in (columns or [])])
+        rs = lib().executeQuerySelectHIP(self.e, items if columns else None, len(columns or []), b"commands", wl.ptr)
+        r = rs.contents
+        names = [r.columnNames[j].decode() for j in range(r.numColumns)]
+        rows = [[r.data[i][j].decode("latin-1") for j in range(r.numColumns)] for i in range(r.numRecords)]
+        out = dict(numRecords=r.numRecords, numColumns=r.numColumns, columns=names, rows=rows,
+                   success=bool(r.success), queryTime=r.queryTime)
+        lib().freeResultSet(rs)
+        return out
+
+    def record(self, i):
+        return self.e.contents.all_records[i].contents
+
+    def close(self):
+        if self.e:
+            lib().destroyEngineHIP(self.e)
+            self.e = None

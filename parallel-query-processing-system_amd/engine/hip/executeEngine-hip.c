@@ -1,0 +1,399 @@
+/* executeEngine-hip.c -- MI355X execute engine (see include/executeEngine-hip.h).
+ *
+ * Host orchestration in C11; every row predicate runs in the HIP filter
+ * kernel behind include/pqps_hip.h.  There is no CPU evaluation path: if the
+ * device or the shim is unavailable the engine prints the reason and exits.
+ *
+ * Reference being replaced: engine/serial/executeEngine-serial.c ("S"):
+ *   executeQuerySelectSerial S:328-528, linearSearchRecords S:854-878,
+ *   evaluateWhereClause S:292-316, executeQueryInsertSerial S:538-617,
+ *   executeQueryDeleteSerial S:627-715, initialize/destroy S:727-814.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "executeEngine-hip.h"
+#include "buildEngine-hip.h"
+#include "hipPredicate.h"
+
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void engine_die(const char *what) {
+    fprintf(stderr, "HIP engine: %s: %s\n", what, pqps_last_error());
+    exit(EXIT_FAILURE);
+}
+
+#define SHIM(call, what) do { if ((call) != PQPS_OK) engine_die(what); } while (0)
+
+/* ---- predicate binding --------------------------------------------------------- */
+
+struct bound_pred {
+    pqps_predicate pred;
+    pqps_column cols[PQPS_MAX_COLUMNS];
+    uint32_t n_cols;
+};
+
+static void bind_where(const struct hipTable *t, const struct whereClauseS *where, struct bound_pred *bp) {
+    struct hipSchema schema;
+    int col_ids[PQPS_MAX_COLUMNS];
+    char err[160];
+    hipSchemaOfTable(t, &schema);
+    if (hipCompileWhere(&schema, where, &bp->pred, col_ids, err, sizeof err) != 0) {
+        fprintf(stderr, "HIP engine: cannot compile WHERE clause: %s\n", err);
+        exit(EXIT_FAILURE);
+    }
+    bp->n_cols = bp->pred.n_columns;
+    for (uint32_t i = 0; i < bp->n_cols; i++) bp->cols[i] = t->col[col_ids[i]];
+}
+
+static void ensure_id_capacity(struct hipTable *t, uint64_t need) {
+    if (need <= t->capacity_ids) return;
+    pqps_free(t->ctx, t->ids_dev);
+    t->capacity_ids = need + need / 8 + 1024;
+    SHIM(pqps_malloc(t->ctx, t->capacity_ids * sizeof(uint32_t), (void **)&t->ids_dev), "result allocation");
+}
+
+/* Inclusive key window of an indexed top-level condition, S:377-424.
+ * v + 1 / v - 1 wrap the way the reference's machine arithmetic does. */
+static void key_window_u64(const char *op, const char *value, uint64_t *lo, uint64_t *hi) {
+    const uint64_t v = strtoull(value, NULL, 10);
+    *lo = 0; *hi = UINT64_MAX;
+    if (strcmp(op, "=") == 0) { *lo = v; *hi = v; }
+    else if (strcmp(op, ">") == 0) *lo = v + 1;
+    else if (strcmp(op, ">=") == 0) *lo = v;
+    else if (strcmp(op, "<") == 0) *hi = v - 1;
+    else if (strcmp(op, "<=") == 0) *hi = v;
+}
+
+static void key_window_i32(const char *op, const char *value, uint64_t *lo, uint64_t *hi) {
+    const int v = atoi(value);
+    int l = INT_MIN, h = INT_MAX;
+    if (strcmp(op, "=") == 0) { l = v; h = v; }
+    else if (strcmp(op, ">") == 0) l = (int)((unsigned)v + 1u);
+    else if (strcmp(op, ">=") == 0) l = v;
+    else if (strcmp(op, "<") == 0) h = (int)((unsigned)v - 1u);
+    else if (strcmp(op, "<=") == 0) h = v;
+    *lo = (uint64_t)(uint32_t)l;
+    *hi = (uint64_t)(uint32_t)h;
+}
+
+/* Row selection of executeQuerySelectSerial, S:358-474, on the device.
+ * Returns the number of result rows; the IDs are left in t->ids_dev. */
+static uint64_t run_selection(struct engineS *engine, struct hipTable *t, struct whereClauseS *where) {
+    struct bound_pred bp;
+    bind_where(t, where, &bp);
+    uint64_t *count_dev = t->count_dev, *range_dev = t->count_dev + 2;
+
+    for (;;) {
+        bool any_index = false;
+        for (struct whereClauseS *wc = where; wc; wc = wc->next) {
+            if (wc->attribute == NULL) continue;                       /* nested node, S:361-364 */
+            for (int i = 0; i < engine->num_indexes; i++) {
+                if (strcmp(wc->attribute, engine->indexed_attributes[i]) != 0) continue;
+                const struct hipIndex *ix = &t->index[i];
+                if (ix->column < 0 || wc->operator == NULL || wc->value == NULL) continue;
+                uint64_t lo, hi;
+                /* only u64 / int indexes are probed by the serial engine, S:377-433 */
+                if (engine->attribute_types[i] == FIELD_UINT64 && t->col[ix->column].width == 8 && ix->key_kind == 0)
+                    key_window_u64(wc->operator, wc->value, &lo, &hi);
+                else if (engine->attribute_types[i] == FIELD_INT && ix->key_kind == 1)
+                    key_window_i32(wc->operator, wc->value, &lo, &hi);
+                else
+                    continue;
+                if (!any_index) SHIM(pqps_memset(t->ctx, count_dev, 0, sizeof(uint64_t), NULL), "counter reset");
+                any_index = true;
+                SHIM(pqps_index_probe(t->ctx, ix->keys_dev, t->col[ix->column].width, ix->key_kind,
+                                      t->n_rows, lo, hi, range_dev, NULL), "index probe");
+                /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
+                SHIM(pqps_filter_gather(t->ctx, bp.cols, bp.n_cols, ix->perm_dev, range_dev, t->n_rows, 0,
+                                        &bp.pred, t->ids_dev, t->capacity_ids, count_dev, NULL), "index filter");
+            }
+        }
+        if (!any_index)                                                /* full scan, S:464-467 */
+            SHIM(pqps_filter_scan(t->ctx, bp.cols, bp.n_cols, t->n_rows, 0, &bp.pred,
+                                  t->ids_dev, t->capacity_ids, count_dev, NULL), "scan filter");
+        SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
+        uint64_t count = 0;
+        SHIM(pqps_download(t->ctx, &count, count_dev, sizeof count, NULL), "count download");
+        if (count <= t->capacity_ids) return count;
+        ensure_id_capacity(t, count);                                  /* duplicates can exceed n rows: retry larger */
+    }
+}
+
+long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
+                                   unsigned int **ids, double *queryTime) {
+    if (!engine || !engine->record_block || !ids) return -1;
+    struct hipTable *t = engine->record_block;
+    const double t0 = now_seconds();
+    const uint64_t count = run_selection(engine, t, whereClause);
+    unsigned int *out = malloc((count ? count : 1) * sizeof *out);
+    if (!out) { perror("Failed to allocate memory for result IDs"); exit(EXIT_FAILURE); }
+    if (count) SHIM(pqps_download(t->ctx, out, t->ids_dev, count * sizeof *out, NULL), "ID download");
+    if (queryTime) *queryTime = now_seconds() - t0;
+    *ids = out;
+    return (long long)count;
+}
+
+long long executeQueryCountHIP(struct engineS *engine, struct whereClauseS *whereClause) {
+    if (!engine || !engine->record_block) return -1;
+    struct hipTable *t = engine->record_block;
+    struct bound_pred bp;
+    bind_where(t, whereClause, &bp);
+    SHIM(pqps_filter_count(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, t->count_dev, NULL), "count filter");
+    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
+    uint64_t count = 0;
+    SHIM(pqps_download(t->ctx, &count, t->count_dev, sizeof count, NULL), "count download");
+    return (long long)count;
+}
+
+/* ---- projection ------------------------------------------------------------------ */
+
+/* get_attribute_string_value, S:216-248. */
+static char *cell_text(const record *r, const char *attribute) {
+    char buf[64];
+    const FieldInfo *fi = get_field_info(attribute);
+    if (!fi) return strdup("NULL");
+    const char *p = (const char *)r + fi->offset;
+    switch (fi->type) {
+    case FIELD_UINT64: snprintf(buf, sizeof buf, "%llu", *(const unsigned long long *)p); return strdup(buf);
+    case FIELD_INT: snprintf(buf, sizeof buf, "%d", *(const int *)p); return strdup(buf);
+    case FIELD_BOOL: return strdup(*(const bool *)p ? "true" : "false");
+    default: return strdup(p);
+    }
+}
+
+static const char *const k_all_columns[12] = {
+    "command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
+    "sudo_used", "working_directory", "user_id", "user_name", "host_name", "risk_level"
+};
+
+struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **selectItems, int numSelectItems,
+                                         const char *tableName, struct whereClauseS *whereClause) {
+    (void)tableName;                                   /* never checked by the reference either */
+    struct resultSetS *rs = malloc(sizeof *rs);
+    if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+    memset(rs, 0, sizeof *rs);
+
+    unsigned int *ids = NULL;
+    double qtime = 0.0;
+    const long long count = executeQuerySelectIdsHIP(engine, whereClause, &ids, &qtime);
+    if (count < 0) { rs->success = false; return rs; }
+
+    rs->numRecords = (int)count;
+    if (selectItems == NULL || numSelectItems == 0) {  /* SELECT *, S:490-492 */
+        selectItems = (const char **)k_all_columns;
+        rs->numColumns = 12;
+    } else {
+        rs->numColumns = numSelectItems;
+    }
+    rs->columnNames = malloc((size_t)rs->numColumns * sizeof(char *));
+    for (int j = 0; j < rs->numColumns; j++) rs->columnNames[j] = strdup(selectItems[j]);
+    rs->data = malloc((count ? (size_t)count : 1) * sizeof(char **));
+    for (long long i = 0; i < count; i++) {
+        const record *r = engine->all_records[ids[i]];
+        rs->data[i] = malloc((size_t)rs->numColumns * sizeof(char *));
+        for (int j = 0; j < rs->numColumns; j++) rs->data[i][j] = cell_text(r, selectItems[j]);
+    }
+    free(ids);
+    rs->columnTypes = calloc((size_t)rs->numColumns, sizeof(FieldType));   /* placeholder, S:524-525 */
+    rs->queryTime = qtime;
+    rs->success = true;
+    return rs;
+}
+
+/* freeResultSet, S:881-908. */
+void freeResultSet(struct resultSetS *result) {
+    if (!result) return;
+    if (result->columnNames) {
+        for (int j = 0; j < result->numColumns; j++) free(result->columnNames[j]);
+        free(result->columnNames);
+    }
+    free(result->columnTypes);
+    if (result->data) {
+        for (int i = 0; i < result->numRecords; i++) {
+            if (!result->data[i]) continue;
+            for (int j = 0; j < result->numColumns; j++) free(result->data[i][j]);
+            free(result->data[i]);
+        }
+        free(result->data);
+    }
+    free(result);
+}
+
+int isAttributeIndexed(struct engineS *engine, const char *attributeName) {
+    for (int i = 0; i < engine->num_indexes; i++)
+        if (strcmp(engine->indexed_attributes[i], attributeName) == 0) return i;
+    return -1;
+}
+
+/* ---- helpers over caller-supplied rows ---------------------------------------------- */
+
+static pqps_ctx *g_adhoc_ctx;
+
+static pqps_ctx *adhoc_ctx(void) {
+    if (!g_adhoc_ctx) {
+        int device = 0;
+        const char *env = getenv("PQPS_DEVICE");
+        if (env) device = atoi(env);
+        SHIM(pqps_ctx_create(device, &g_adhoc_ctx), "cannot create a device context");
+    }
+    return g_adhoc_ctx;
+}
+
+/* linearSearchRecords, S:854-878: the rows are columnarised, filtered on the
+ * GPU (input order kept) and the surviving pointers returned. */
+record **linearSearchRecords(record **records, int num_records, struct whereClauseS *whereClause,
+                             int *matchingRecords) {
+    *matchingRecords = 0;
+    struct hipTable *t = hipTableFromRows(adhoc_ctx(), records, (size_t)(num_records > 0 ? num_records : 0));
+    struct bound_pred bp;
+    bind_where(t, whereClause, &bp);
+    SHIM(pqps_filter_scan(t->ctx, bp.cols, bp.n_cols, t->n_rows, 0, &bp.pred,
+                          t->ids_dev, t->capacity_ids, t->count_dev, NULL), "scan filter");
+    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
+    uint64_t count = 0;
+    SHIM(pqps_download(t->ctx, &count, t->count_dev, sizeof count, NULL), "count download");
+    uint32_t *ids = malloc((count ? count : 1) * sizeof *ids);
+    record **out = malloc((count ? count : 1) * sizeof *out);
+    if (!ids || !out) { perror("Failed to allocate memory for results"); exit(EXIT_FAILURE); }
+    if (count) SHIM(pqps_download(t->ctx, ids, t->ids_dev, count * sizeof *ids, NULL), "ID download");
+    for (uint64_t i = 0; i < count; i++) out[i] = records[ids[i]];
+    free(ids);
+    hipTableFree(t, 0);
+    *matchingRecords = (int)count;
+    return out;
+}
+
+/* evaluateWhereClause, S:292-316, for one row: a one-row table through the same kernel. */
+bool evaluateWhereClause(record *r, struct whereClauseS *wc) {
+    if (wc == NULL) return true;
+    int n = 0;
+    record *rows[1] = { r };
+    record **hit = linearSearchRecords(rows, 1, wc, &n);
+    free(hit);
+    return n == 1;
+}
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+
+struct engineS *initializeEngineHIP(int num_indexes, const char *indexed_attributes[],
+                                    const int attribute_types[], const char *datafile,
+                                    const char *tableName) {
+    struct engineS *engine = malloc(sizeof *engine);
+    if (!engine) { perror("Failed to allocate memory for engine"); exit(EXIT_FAILURE); }
+    memset(engine, 0, sizeof *engine);
+    engine->tableName = strdup(tableName ? tableName : "");
+    if (!datafile) datafile = "../data/commands_50k.csv";          /* S:757 */
+    engine->datafile = strdup(datafile);
+    engine->all_records = getAllRecordsFromFileHIP(datafile, &engine->num_records, &engine->record_block);
+    buildDeviceTableHIP(engine);                                   /* exits loudly without a GPU */
+    for (int i = 0; i < num_indexes; i++) {
+        if (!makeIndexHIP(engine, indexed_attributes[i], attribute_types[i]))
+            fprintf(stderr, "Failed to create index for attribute: %s\n", indexed_attributes[i]);
+    }
+    return engine;
+}
+
+void destroyEngineHIP(struct engineS *engine) {
+    if (!engine) { fprintf(stderr, "Attempted to destroy a NULL engine pointer\n"); return; }
+    destroyDeviceTableHIP(engine);                                 /* frees the row block too */
+    free(engine->bplus_tree_roots);
+    if (engine->indexed_attributes) {
+        for (int i = 0; i < engine->num_indexes; i++) free(engine->indexed_attributes[i]);
+        free(engine->indexed_attributes);
+    }
+    free(engine->attribute_types);
+    free(engine->all_records);
+    free(engine->tableName);
+    free(engine->datafile);
+    free(engine);
+}
+
+bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const char *attributeName,
+                          int attributeType) {
+    (void)tableName;
+    return makeIndexHIP(engine, attributeName, attributeType);
+}
+
+/* ---- mutation (kept in step with the CSV like the reference) ------------------------------ */
+
+static void write_csv_row(FILE *f, const record *r) {           /* S:562, S:687 */
+    fprintf(f, "%llu,%s,%s,%s,%d,%s,%d,%s,%d,%s,%s,%d\n", r->command_id, r->raw_command, r->base_command,
+            r->shell_type, r->exit_code, r->timestamp, r->sudo_used, r->working_directory, r->user_id,
+            r->user_name, r->host_name, r->risk_level);
+}
+
+/* executeQueryInsertSerial, S:538-617. */
+bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const record *r) {
+    (void)tableName;
+    if (r->command_id == 0 || !r->raw_command[0] || !r->base_command[0] || !r->shell_type[0] ||
+        !r->timestamp[0] || !r->working_directory[0] || !r->user_name[0] || !r->host_name[0])
+        return false;                                              /* S:544-551 */
+    FILE *f = fopen(engine->datafile, "a");
+    if (!f) return false;
+    write_csv_row(f, r);
+    fclose(f);
+
+    struct hipTable *t = engine->record_block;
+    const size_t n = (size_t)engine->num_records;
+    record *block = realloc(t->row_block, (n + 1) * sizeof *block);
+    record **rows = realloc(engine->all_records, (n + 1) * sizeof *rows);
+    if (!block || !rows) return false;
+    block[n] = *r;
+    for (size_t i = 0; i <= n; i++) rows[i] = &block[i];
+    t->row_block = block;
+    engine->all_records = rows;
+    engine->num_records = (int)(n + 1);
+    rebuildDeviceTableHIP(engine);
+    return true;
+}
+
+/* executeQueryDeleteSerial, S:627-715: the per-row decision is the GPU flag
+ * kernel (the flag-array shape of engine/omp/executeEngine-omp.c:708-732). */
+struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tableName,
+                                         struct whereClauseS *whereClause) {
+    (void)tableName;
+    struct resultSetS *rs = calloc(1, sizeof *rs);
+    if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+    const double t0 = now_seconds();
+    struct hipTable *t = engine->record_block;
+    const size_t n = (size_t)engine->num_records;
+    struct bound_pred bp;
+    bind_where(t, whereClause, &bp);
+    uint8_t *flags_dev = NULL, *flags = malloc(t->capacity_rows);
+    SHIM(pqps_malloc(t->ctx, t->capacity_rows, (void **)&flags_dev), "flag allocation");
+    SHIM(pqps_filter_flags(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, flags_dev, t->count_dev, NULL), "flag filter");
+    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
+    if (n) SHIM(pqps_download(t->ctx, flags, flags_dev, n, NULL), "flag download");
+    pqps_free(t->ctx, flags_dev);
+
+    size_t keep = 0, deleted = 0;
+    record *block = t->row_block;
+    for (size_t i = 0; i < n; i++) {
+        if (flags[i]) { deleted++; continue; }
+        if (keep != i) block[keep] = block[i];
+        keep++;
+    }
+    free(flags);
+    for (size_t i = 0; i < keep; i++) engine->all_records[i] = &block[i];
+    engine->num_records = (int)keep;
+
+    FILE *f = fopen(engine->datafile, "w");                       /* S:683-701: no header written */
+    if (f) {
+        for (size_t i = 0; i < keep; i++) write_csv_row(f, &block[i]);
+        fclose(f);
+    }
+    if (deleted) rebuildDeviceTableHIP(engine);
+    rs->numRecords = (int)deleted;
+    rs->queryTime = now_seconds() - t0;
+    rs->success = true;
+    return rs;
+}

@@ -13,139 +13,35 @@ The struct classes mirror include/logType.h and include/executeEngine-serial.h
 from __future__ import annotations
 
 import ctypes as C
-import os
+import importlib.util
 import pathlib
 import subprocess
+import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 PKG = ROOT / "parallel-query-processing-system_amd"
 ORACLE_DIR = ROOT / "oracle"
 GOLDEN = ROOT / "tests" / "golden"
 
-US, RS = "\x1f", "\x1e"
 
-COLUMNS = ["command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
-           "sudo_used", "working_directory", "user_id", "user_name", "host_name", "risk_level"]
+def load_package():
+    """Imports parallel-query-processing-system_amd/ (not a valid identifier) as `pqps_amd`."""
+    if "pqps_amd" in sys.modules:
+        return sys.modules["pqps_amd"]
+    spec = importlib.util.spec_from_file_location("pqps_amd", PKG / "__init__.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["pqps_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+pq = load_package()
+# struct mirrors and WHERE-list builder live with the product binding
+Record, WhereClause, ResultSet, Engine, WhereList = pq.Record, pq.WhereClause, pq.ResultSet, pq.EngineS, pq.WhereList
+COLUMNS, DEFAULT_INDEXES = pq.COLUMNS, pq.DEFAULT_INDEXES
 FIELD_UINT64, FIELD_INT, FIELD_STRING, FIELD_BOOL = 0, 1, 2, 3
-SCHEMA_TYPES = dict(command_id=FIELD_UINT64, exit_code=FIELD_INT, user_id=FIELD_INT,
-                    risk_level=FIELD_INT, sudo_used=FIELD_BOOL)
-DEFAULT_INDEXES = [("command_id", 0), ("user_id", 1), ("risk_level", 1), ("exit_code", 1), ("sudo_used", 3)]
 
-
-class Record(C.Structure):
-    _fields_ = [
-        ("command_id", C.c_ulonglong),
-        ("raw_command", C.c_char * 512),
-        ("base_command", C.c_char * 100),
-        ("shell_type", C.c_char * 20),
-        ("exit_code", C.c_int),
-        ("timestamp", C.c_char * 30),
-        ("sudo_used", C.c_bool),
-        ("working_directory", C.c_char * 200),
-        ("user_id", C.c_int),
-        ("user_name", C.c_char * 50),
-        ("host_name", C.c_char * 100),
-        ("risk_level", C.c_int),
-    ]
-
-
-assert C.sizeof(Record) == 1040
-
-
-class WhereClause(C.Structure):
-    pass
-
-
-WhereClause._fields_ = [
-    ("attribute", C.c_char_p),
-    ("operator", C.c_char_p),
-    ("value", C.c_char_p),
-    ("value_type", C.c_int),
-    ("next", C.POINTER(WhereClause)),
-    ("logical_op", C.c_char_p),
-    ("sub", C.POINTER(WhereClause)),
-]
-assert C.sizeof(WhereClause) == 56
-
-
-class ResultSet(C.Structure):
-    _fields_ = [
-        ("numRecords", C.c_int),
-        ("numColumns", C.c_int),
-        ("columnNames", C.POINTER(C.c_char_p)),
-        ("columnTypes", C.POINTER(C.c_int)),
-        ("data", C.POINTER(C.POINTER(C.c_char_p))),
-        ("queryTime", C.c_double),
-        ("success", C.c_bool),
-    ]
-
-
-assert C.sizeof(ResultSet) == 48
-
-
-class Engine(C.Structure):
-    _fields_ = [
-        ("tableName", C.c_char_p),
-        ("bplus_tree_roots", C.c_void_p),
-        ("num_indexes", C.c_int),
-        ("indexed_attributes", C.POINTER(C.c_char_p)),
-        ("attribute_types", C.POINTER(C.c_int)),
-        ("all_records", C.POINTER(C.POINTER(Record))),
-        ("num_records", C.c_int),
-        ("datafile", C.c_char_p),
-        ("record_block", C.c_void_p),
-    ]
-
-
-assert C.sizeof(Engine) == 72
-
-
-# --------------------------------------------------------------------------
-# WHERE lists.  A python "chain" is a list alternating items and the strings
-# "AND"/"OR";  an item is ("attr", "op", "value") or a nested chain (list).
-#   [("sudo_used","=","TRUE"), "OR", [("risk_level","=","5"), "AND", ("shell_type","=","bash")]]
-# --------------------------------------------------------------------------
-class WhereList:
-    """Owns the ctypes nodes of one whereClauseS list (keeps them alive)."""
-
-    def __init__(self, chain):
-        self._keep = []
-        self.head = self._build(chain)
-
-    def _build(self, chain):
-        if not chain:
-            return None
-        items = chain[0::2]
-        ops = chain[1::2]
-        nodes = []
-        for it in items:
-            n = WhereClause()
-            if isinstance(it, list):
-                n.attribute = None
-                n.operator = None
-                n.value = None
-                sub = self._build(it)
-                n.sub = C.pointer(sub) if sub is not None else None
-            else:
-                a, o, v = it[:3]
-                n.attribute = a.encode() if a is not None else None
-                n.operator = o.encode() if o is not None else None
-                n.value = v.encode("latin-1") if v is not None else None
-                n.value_type = it[3] if len(it) > 3 else 0
-            self._keep.append(n)
-            nodes.append(n)
-        for i, n in enumerate(nodes):
-            if i + 1 < len(nodes):
-                n.next = C.pointer(nodes[i + 1])
-                op = ops[i]
-                n.logical_op = op.encode() if op is not None else None
-            else:
-                n.logical_op = None
-        return nodes[0]
-
-    @property
-    def ptr(self):
-        return C.byref(self.head) if self.head is not None else None
+US, RS = "\x1f", "\x1e"
 
 
 def parse_where_dump(text: str):
@@ -406,3 +302,70 @@ class OracleTable:
     def project(self, ids, columns):
         cols = columns if columns else COLUMNS
         return [[self.cell(r, c) for c in cols] for r in ids]
+
+
+# --------------------------------------------------------------------------
+# Synthetic tables on the host (CPU twin of pqps_synth_generate) + the oracle's
+# columnar scan over them.
+# --------------------------------------------------------------------------
+class OrcColumns(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_uint64),
+        ("command_id", C.c_void_p),
+        ("exit_code", C.c_void_p), ("user_id", C.c_void_p), ("risk_level", C.c_void_p),
+        ("sudo_used", C.c_void_p),
+        ("str_code", C.c_void_p * 7),
+        ("str_code_width", C.c_int * 7),
+        ("str_dict", C.POINTER(C.c_char_p) * 7),
+    ]
+
+
+# oracle string-column order: raw_command, base_command, shell_type, timestamp, working_directory, user_name, host_name
+ORC_STR = ["raw_command", "base_command", "shell_type", "timestamp", "working_directory", "user_name", "host_name"]
+
+
+class HostSynth:
+    """Host copy of rows [row0, row0+n) of the synthetic table (numpy arrays), same bits as the device."""
+
+    def __init__(self, n, seed=0x5EED, row0=0):
+        import numpy as np
+        self.n, self.seed, self.row0 = n, seed, row0
+        L = pq.lib()
+        cdf, shell = pq.synth_user_tables(seed)
+        self.arr = {}
+        sc = pq.SynthCols()
+        dt = dict(command_id=np.uint64, exit_code=np.int32, user_id=np.int32, risk_level=np.int32,
+                  sudo_used=np.uint8, shell_type=np.uint8, user_name=np.uint16, host_name=np.uint8, base_command=np.uint8)
+        for name, field, _w in pq.SYNTH_LAYOUT:
+            a = np.zeros(max(n, 1), dtype=dt[name])
+            self.arr[name] = a
+            setattr(sc, field, a.ctypes.data)
+        L.pqps_synth_generate_host(seed, row0, n, cdf, shell, C.byref(sc))
+        for k in self.arr:
+            self.arr[k] = self.arr[k][:n]
+        self._dicts = {}
+        for name, vals in (("shell_type", pq.SYNTH_SHELLS), ("user_name", pq.SYNTH_USERS_DICT),
+                           ("host_name", pq.SYNTH_HOSTS), ("base_command", pq.SYNTH_BASES)):
+            arr = (C.c_char_p * len(vals))(*vals)
+            self._dicts[name] = arr
+
+    def orc_columns(self):
+        oc = OrcColumns()
+        oc.n_rows = self.n
+        for name in ("command_id", "exit_code", "user_id", "risk_level", "sudo_used"):
+            setattr(oc, name, self.arr[name].ctypes.data)
+        for k, name in enumerate(ORC_STR):
+            if name in self._dicts:
+                oc.str_code[k] = self.arr[name].ctypes.data
+                oc.str_code_width[k] = self.arr[name].dtype.itemsize
+                oc.str_dict[k] = C.cast(self._dicts[name], C.POINTER(C.c_char_p))
+        return oc
+
+    def oracle_scan(self, chain, id_base=0, nthreads=1):
+        import numpy as np
+        lib = load_oracle()
+        wl = WhereList(chain)
+        oc = self.orc_columns()
+        out = np.zeros(max(self.n, 1), dtype=np.uint32)
+        k = lib.orc_scan_columns(C.byref(oc), wl.ptr, id_base, out.ctypes.data_as(C.POINTER(C.c_uint32)), self.n, nthreads)
+        return out[:k]

@@ -1,0 +1,376 @@
+"""Parity of the HIP path with the oracle, through the C-ABI, on a real MI355X.
+
+  * shim level  (include/pqps_hip.h): synthetic tables generated on the device,
+    the same bits regenerated on the host, oracle scan vs pqps_filter_* --
+    bit-exact row-ID sequences; sizes straddle tile / chunk boundaries.
+  * engine level (include/executeEngine-hip.h): every committed golden vector
+    the REAL reference produced (tests/golden/select_golden.json) -- row IDs and
+    the sha256 of every projected cell; index leaf order; known-answer tests of
+    the reference's tests/*.c.
+  * full size (BASELINE configs[1], 100 M rows): size-independent properties --
+    ascending IDs, count == COUNT(*) == popcount(flags), sampled membership
+    against the host twin, shard concatenation == whole-table result.
+"""
+import ctypes as C
+import hashlib
+import json
+import random
+
+import numpy as np
+import pytest
+
+import qpelib as q
+
+pq = q.pq
+pytestmark = pytest.mark.gpu
+
+SELECT = json.loads((q.GOLDEN / "select_golden.json").read_text())
+INDEX_CONFIGS = {
+    "none": [],
+    "default": pq.DEFAULT_INDEXES,
+    "cmdid": [("command_id", 0)],
+    "risk": [("risk_level", 1)],
+    "risk_twice": [("risk_level", 1), ("risk_level", 1)],
+}
+
+QUERIES = {
+    "S1": [("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")],
+    "Q_A": [("risk_level", ">", "3")],
+    "Q_B": [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")],
+    "Q_C": [("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1500"), "OR", ("risk_level", "=", "5")],
+    "S7": [("sudo_used", "=", "TRUE"), "OR", [("risk_level", "=", "5"), "AND", ("shell_type", "=", "bash")]],
+    "S8": [("user_id", "=", "1001"), "OR", [("user_name", "=", "student1002"), "AND", ("shell_type", "=", "zsh")]],
+    "cid_range": [("command_id", ">=", "1000"), "AND", ("command_id", "<", "70000")],
+    "all": [],
+    "none": [("risk_level", ">", "9")],
+    "neq": [("risk_level", "!=", "1")],
+    "seven_leaves": [("risk_level", "=", "1"), "OR", ("risk_level", "=", "2"), "AND", ("exit_code", "=", "0"), "OR",
+                     [("host_name", "<", "labpc-05"), "AND", ("shell_type", "!=", "zsh"), "AND", ("user_id", "<", "1900")],
+                     "OR", ("sudo_used", "=", "1")],
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pq.Context(0)
+    yield c
+    c.close()
+
+
+class DeviceOut:
+    def __init__(self, ctx, cap):
+        self.ctx, self.cap = ctx, cap
+        self.ids = ctx.malloc(max(cap, 1) * 4)
+        self.count = ctx.malloc(64)
+        self.flags = None
+
+    def read_count(self):
+        v = C.c_uint64()
+        self.ctx.download(C.byref(v), self.count, 8)
+        return v.value
+
+    def read_ids(self, k):
+        a = np.zeros(max(k, 1), dtype=np.uint32)
+        if k:
+            self.ctx.download(a.ctypes.data, self.ids, 4 * k)
+        return a[:k]
+
+    def free(self):
+        self.ctx.free(self.ids)
+        self.ctx.free(self.count)
+
+
+def gpu_scan(ctx, table, chain, out, id_base=0):
+    pred, cols, nc, _ = table.bind(chain)
+    pq.check(pq.lib().pqps_filter_scan(ctx.h, cols, nc, table.n, id_base, C.byref(pred), out.ids, out.cap, out.count, None),
+             "pqps_filter_scan")
+    ctx.sync()
+    k = out.read_count()
+    assert k <= out.cap
+    return out.read_ids(k)
+
+
+def gpu_count(ctx, table, chain, out):
+    pred, cols, nc, _ = table.bind(chain)
+    pq.check(pq.lib().pqps_filter_count(ctx.h, cols, nc, table.n, C.byref(pred), out.count, None), "pqps_filter_count")
+    ctx.sync()
+    return out.read_count()
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 63, 64, 255, 256, 257, 1023, 4095, 4096, 4097, 8191, 12288, 100001, 1 << 20, (1 << 21) + 17])
+def test_scan_matches_oracle_across_sizes(ctx, n):
+    dev = pq.SyntheticTable(ctx, n, seed=0x5EED)
+    host = q.HostSynth(n, seed=0x5EED)
+    out = DeviceOut(ctx, n + 8)
+    try:
+        for name, chain in QUERIES.items():
+            got = gpu_scan(ctx, dev, chain, out)
+            want = host.oracle_scan(chain)
+            assert got.shape == want.shape and np.array_equal(got, want), (name, n)
+            assert gpu_count(ctx, dev, chain, out) == len(want), (name, n)
+    finally:
+        out.free()
+        dev.free()
+
+
+def test_device_generator_equals_host_twin(ctx):
+    n = 300_007
+    dev = pq.SyntheticTable(ctx, n, seed=77, row0=123_456_789)
+    host = q.HostSynth(n, seed=77, row0=123_456_789)
+    for name, _f, w in pq.SYNTH_LAYOUT:
+        a = np.zeros(n, dtype=host.arr[name].dtype)
+        ctx.download(a.ctypes.data, dev.ptr[name], n * w)
+        assert np.array_equal(a, host.arr[name]), name
+    # distributions of SURVEY App. B hold roughly
+    r = host.arr["risk_level"]
+    assert abs((r == 1).mean() - 0.568) < 0.01 and abs((r > 3).mean() - 0.044) < 0.005
+    assert abs(host.arr["sudo_used"].mean() - 0.068) < 0.01
+    dev.free()
+
+
+def test_id_base_and_shard_concatenation(ctx):
+    """Row-range shards (mpi:703-715 partition) filtered separately and concatenated in
+    rank order give the whole-table answer -- the all-gatherv merge shape."""
+    n, world = 1_000_003, 8
+    whole = q.HostSynth(n, seed=5).oracle_scan(QUERIES["Q_B"])
+    parts = []
+    for r in range(world):
+        s, c = C.c_uint64(), C.c_uint64()
+        pq.lib().pqps_partition(n, world, r, C.byref(s), C.byref(c))
+        dev = pq.SyntheticTable(ctx, c.value, seed=5, row0=s.value)
+        out = DeviceOut(ctx, c.value + 8)
+        parts.append(gpu_scan(ctx, dev, QUERIES["Q_B"], out, id_base=s.value))
+        out.free()
+        dev.free()
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+def test_flags_mode(ctx):
+    n = 70_001
+    dev = pq.SyntheticTable(ctx, n, seed=9)
+    host = q.HostSynth(n, seed=9)
+    flags_dev = ctx.malloc(n + 4096)
+    cnt = ctx.malloc(64)
+    for name in ("Q_A", "S7", "all", "none", "seven_leaves"):
+        pred, cols, nc, _ = dev.bind(QUERIES[name])
+        pq.check(pq.lib().pqps_filter_flags(ctx.h, cols, nc, n, C.byref(pred), flags_dev, cnt, None))
+        ctx.sync()
+        f = np.zeros(n, dtype=np.uint8)
+        ctx.download(f.ctypes.data, flags_dev, n)
+        want = np.zeros(n, dtype=np.uint8)
+        want[host.oracle_scan(QUERIES[name])] = 1
+        assert np.array_equal(f, want), name
+    ctx.free(flags_dev)
+    ctx.free(cnt)
+    dev.free()
+
+
+def test_random_trees_on_device(ctx):
+    import test_predicate_compile as tpc
+    n = 50_000
+    dev = pq.SyntheticTable(ctx, n, seed=3)
+    host = q.HostSynth(n, seed=3)
+    out = DeviceOut(ctx, n + 8)
+    rng = random.Random(2024)
+    leaves = [l for l in tpc.LEAVES if l[0] not in ("working_directory", "timestamp", "raw_command")]
+    done = 0
+    for _ in range(150):
+        saved, tpc.LEAVES = tpc.LEAVES, leaves
+        try:
+            chain = tpc.random_chain(rng, depth=3, max_items=5)
+        finally:
+            tpc.LEAVES = saved
+        if tpc.count_leaves(chain) > 40:
+            continue
+        try:
+            got = gpu_scan(ctx, dev, chain, out)
+        except pq.PqpsError as e:
+            assert "limit" in str(e)
+            continue
+        assert np.array_equal(got, host.oracle_scan(chain)), chain
+        done += 1
+    assert done > 100
+    out.free()
+    dev.free()
+
+
+def test_capacity_overflow_is_reported_not_written(ctx):
+    n = 10_000
+    dev = pq.SyntheticTable(ctx, n, seed=1)
+    out = DeviceOut(ctx, 16)
+    pred, cols, nc, _ = dev.bind([])
+    guard = ctx.malloc(4 * 64)
+    pq.check(pq.lib().pqps_filter_scan(ctx.h, cols, nc, n, 0, C.byref(pred), out.ids, 16, out.count, None))
+    ctx.sync()
+    assert out.read_count() == n                       # true count, caller sees it exceeds capacity
+    assert list(out.read_ids(16)) == list(range(16))
+    ctx.free(guard)
+    out.free()
+    dev.free()
+
+
+# ---- engine level: golden vectors of the real reference -------------------------------
+def sha_rows(rows):
+    h = hashlib.sha256()
+    for r in rows:
+        for c in r:
+            h.update(c.encode("latin-1"))
+            h.update(b"\x1f")
+        h.update(b"\x1e")
+    return h.hexdigest()
+
+
+_engines = {}
+
+
+def engine_for(csv, cfg):
+    key = (csv, cfg)
+    if key not in _engines:
+        _engines[key] = pq.HipEngine(q.GOLDEN / csv, INDEX_CONFIGS[cfg])
+    return _engines[key]
+
+
+@pytest.mark.parametrize("case", SELECT, ids=[f"{c['csv'][:4]}-{c['name']}-{c['indexes']}" for c in SELECT])
+def test_engine_select_matches_reference_golden(case):
+    eng = engine_for(case["csv"], case["indexes"])
+    chain = q.chain_from_jsonable(case["where"])
+    ids = eng.select_ids(chain)
+    assert len(ids) == case["num_records"]
+    if "ids" in case:
+        assert ids == case["ids"]
+    sql = case["sql"]
+    sel = sql[len("SELECT "):sql.index(" FROM ")]
+    cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]
+    res = eng.select(cols, chain)
+    assert res["success"] and res["numRecords"] == case["num_records"]
+    assert sha_rows(res["rows"]) == case["rows_sha256"]
+    if case.get("columns"):
+        assert res["columns"] == case["columns"]
+    if case["indexes"] == "none":
+        assert eng.count(chain) == case["num_records"]
+
+
+def test_engine_index_order_matches_reference_btree(ctx):
+    gold = json.loads((q.GOLDEN / "index_order_golden.json").read_text())
+    for csv, per_attr in gold.items():
+        attrs = [("command_id", 0), ("user_id", 1), ("risk_level", 1), ("exit_code", 1), ("sudo_used", 3),
+                 ("shell_type", 2), ("user_name", 2)]
+        eng = pq.HipEngine(q.GOLDEN / csv, attrs)
+        # read the device permutations back through the table handle
+        tbl = C.cast(eng.e.contents.record_block, C.POINTER(HipTable)).contents
+        for i, (a, _t) in enumerate(attrs):
+            perm = np.zeros(max(eng.n, 1), dtype=np.uint32)
+            if eng.n:
+                ctx.download(perm.ctypes.data, tbl.index[i].perm_dev, 4 * eng.n)
+            assert list(perm[:eng.n]) == per_attr[a], (csv, a)
+        eng.close()
+
+
+class HipDictionary(C.Structure):
+    _fields_ = [("count", C.c_int), ("values", C.c_void_p), ("storage", C.c_void_p)]
+
+
+class HipIndex(C.Structure):
+    _fields_ = [("column", C.c_int), ("key_kind", C.c_int), ("perm_dev", C.c_void_p), ("keys_dev", C.c_void_p)]
+
+
+class HipTable(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("n_rows", C.c_uint64), ("capacity_rows", C.c_uint64),
+                ("col", pq.Column * 12), ("dict", HipDictionary * 12), ("index", C.POINTER(HipIndex)),
+                ("ids_dev", C.c_void_p), ("capacity_ids", C.c_uint64), ("count_dev", C.c_void_p),
+                ("row_block", C.c_void_p)]
+
+
+def test_kat_reference_unit_tests():
+    """tests/executeEngine-serial-test.c:29-114 through evaluateWhereClause (HIP, one-row table)."""
+    L = pq.lib()
+    r = pq.Record()
+    r.command_id, r.risk_level, r.user_id, r.sudo_used, r.exit_code = 100, 5, 10, True, 0
+    r.user_name, r.raw_command, r.base_command, r.shell_type = b"admin", b"ls -la", b"ls", b"bash"
+    r.timestamp, r.working_directory, r.host_name = b"2023-01-01", b"/home/admin", b"localhost"
+    for chain, want in [
+        ([("risk_level", ">", "3")], True),
+        ([[("risk_level", ">", "3"), "AND", ("user_id", "=", "10")]], True),
+        ([[("risk_level", ">", "10")], "OR", [("user_id", "=", "10")]], True),
+        ([[("risk_level", ">", "10")], "AND", [("user_id", "=", "10")]], False),
+        ([("user_name", "=", "admin"), "AND", ("sudo_used", "=", "true")], True),
+    ]:
+        wl = pq.WhereList(chain)
+        assert L.evaluateWhereClause(C.byref(r), wl.ptr) is want
+
+
+def test_kat_duplicates_and_ranges(tmp_path):
+    """tests/duplicate-test.c:37-54 and tests/bplus-serial-test.c:40-43 through the HIP engine."""
+    p = tmp_path / "dup.csv"
+    p.write_text(
+        "command_id,raw_command,base_command,shell_type,exit_code,timestamp,sudo_used,working_directory,user_id,user_name,host_name,risk_level\n"
+        "1,cmd1,base,bash,0,ts,0,wd,1001,user,host,1\n2,cmd2,base,bash,0,ts,0,wd,1001,user,host,1\n"
+        "3,cmd3,base,bash,0,ts,0,wd,1001,user,host,2\n4,cmd4,base,bash,0,ts,0,wd,1001,user,host,1\n")
+    eng = pq.HipEngine(p, [("risk_level", 1)])
+    assert eng.n == 4
+    assert eng.select_ids([("risk_level", "=", "1")]) == [3, 1, 0]
+    assert eng.select_ids([("risk_level", "=", "2")]) == [2]
+    eng.close()
+    p2 = tmp_path / "r.csv"
+    p2.write_text("h\n" + "".join(f"{k},c,b,bash,0,ts,0,wd,1,u,h,1\n" for k in (5, 15, 25, 35, 45)))
+    eng = pq.HipEngine(p2, [("command_id", 0)])
+    ids = eng.select_ids([("command_id", ">=", "10"), "AND", ("command_id", "<=", "30")])
+    assert [eng.record(i).command_id for i in ids] == [15, 25, 15, 25]
+    ids = eng.select_ids([("command_id", ">=", "5"), "AND", ("command_id", "<=", "45")])
+    assert sorted(eng.record(i).command_id for i in ids) == [5, 5, 15, 15, 25, 25, 35, 35, 45, 45]
+    eng.close()
+
+
+def test_linear_search_records_keeps_input_order():
+    t = q.OracleTable(q.GOLDEN / "commands_2k.csv", [])
+    L = pq.lib()
+    order = list(range(t.n))
+    random.Random(7).shuffle(order)
+    order = order[:500]
+    ptrs = (C.POINTER(pq.Record) * len(order))(*[C.pointer(t.rows[i]) for i in order])
+    chain = [("risk_level", ">", "1"), "AND", ("shell_type", "=", "bash")]
+    wl = pq.WhereList(chain)
+    n = C.c_int()
+    res = L.linearSearchRecords(ptrs, len(order), wl.ptr, C.byref(n))
+    got = [res[i].contents.command_id for i in range(n.value)]
+    want = [t.rows[i].command_id for i in order if q.load_oracle().orc_eval_where(C.byref(t.rows[i]), wl.ptr)]
+    assert got == want
+    L.free(res)
+
+
+# ---- full size: BASELINE configs[1] = 100 M rows on one GPU --------------------------------
+def test_full_size_properties(ctx):
+    n = 100_000_000
+    dev = pq.SyntheticTable(ctx, n, seed=0x5EED, columns=["risk_level", "sudo_used", "user_name", "exit_code", "user_id"])
+    out = DeviceOut(ctx, n // 4)
+    flags_dev = ctx.malloc(n + 4096)
+    rng = np.random.default_rng(1)
+    try:
+        for name in ("S1", "Q_A", "Q_B", "Q_C"):
+            chain = QUERIES[name]
+            ids = gpu_scan(ctx, dev, chain, out)
+            k = len(ids)
+            assert k > 0 and np.all(ids[1:] > ids[:-1]), name              # strictly ascending
+            assert gpu_count(ctx, dev, chain, out) == k, name              # COUNT(*) agrees
+            pred, cols, nc, _ = dev.bind(chain)
+            pq.check(pq.lib().pqps_filter_flags(ctx.h, cols, nc, n, C.byref(pred), flags_dev, out.count, None))
+            ctx.sync()
+            assert out.read_count() == k
+            f = np.zeros(n, dtype=np.uint8)
+            ctx.download(f.ctypes.data, flags_dev, n)
+            assert int(f.sum()) == k and np.array_equal(np.nonzero(f)[0].astype(np.uint32), ids), name
+            # membership of sampled rows against the host twin / oracle, row by row
+            sample = np.unique(np.concatenate([rng.integers(0, n, 2000), ids[rng.integers(0, k, 2000)],
+                                               [0, 1, 4095, 4096, n - 1, n - 4097]]))
+            member = np.isin(sample, ids)
+            for row, m in zip(sample, member):
+                h = q.HostSynth(1, seed=0x5EED, row0=int(row))
+                assert (len(h.oracle_scan(chain)) == 1) == bool(m), (name, row)
+            # a prefix of the table is bit-exact against the oracle
+            m = 3_000_000
+            want = q.HostSynth(m, seed=0x5EED).oracle_scan(chain)
+            assert np.array_equal(ids[:len(want)], want) and (len(want) == k or ids[len(want)] >= m)
+    finally:
+        ctx.free(flags_dev)
+        out.free()
+        dev.free()
