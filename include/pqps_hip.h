@@ -50,7 +50,7 @@ extern "C" {
 #define PQPS_MAX_COLUMNS  12   /* columns of `record` (include/logType.h)          */
 #define PQPS_MAX_LEAVES   32   /* leaf comparisons in one WHERE tree               */
 #define PQPS_TT_LEAVES     6   /* <= 6 leaves: 64-entry truth table path           */
-#define PQPS_TILE_ROWS  4096   /* rows one workgroup handles per look-back tile    */
+#define PQPS_TILE_ROWS  4096   /* column buffers are padded to a multiple of this  */
 
 /* One device-resident column.  `width` in {1,2,4,8} bytes per row; values are
  * compared as unsigned after the host has biased signed columns (see
@@ -97,12 +97,14 @@ int  pqps_ctx_create(int device, pqps_ctx **out);
 void pqps_ctx_destroy(pqps_ctx *ctx);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
-/* Per-launch HIP-event timing of the filter kernel itself (events recorded on
- * the launch stream right around the kernel, up to 4096 launches per reset).
- * pqps_ctx_kernel_time waits for the recorded launches, returns the sum of
- * their durations and their number, and resets the recorder. */
+/* Per-launch HIP-event timing of the filter (events recorded on the launch
+ * stream, up to 4096 launches per reset).  pqps_ctx_kernel_time waits for the
+ * recorded launches and returns: *eval_ms = sum of the durations of the
+ * evaluate kernel alone (K1, the only kernel that reads the table),
+ * *total_ms = sum over the whole K1 -> K2 -> K3 pipeline, and their number;
+ * it then resets the recorder. */
 int  pqps_ctx_set_timing(pqps_ctx *ctx, int enable);
-int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *total_ms, int *launches);
+int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *launches);
 /* Fills name (<=63 chars), CU count and total HBM bytes of the ctx device. */
 int  pqps_device_info(pqps_ctx *ctx, char *name64, int *compute_units, uint64_t *hbm_bytes);
 

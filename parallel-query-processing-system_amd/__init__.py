@@ -212,7 +212,7 @@ def lib():
     L.pqps_ctx_destroy.restype = None
     L.pqps_ctx_sync.argtypes = [vp, vp]
     L.pqps_ctx_set_timing.argtypes = [vp, C.c_int]
-    L.pqps_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pqps_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.pqps_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(u64)]
     L.pqps_malloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.pqps_free.argtypes = [vp, vp]
@@ -354,10 +354,10 @@ class Context:
         check(lib().pqps_ctx_set_timing(self.h, 1 if on else 0))
 
     def kernel_time(self):
-        """-> (sum of filter-kernel durations in ms, number of launches) since the last call."""
-        ms, k = C.c_double(), C.c_int()
-        check(lib().pqps_ctx_kernel_time(self.h, C.byref(ms), C.byref(k)))
-        return ms.value, k.value
+        """-> (ms in the evaluate kernel K1, ms in K1..K3, launches) summed since the last call."""
+        ev, tot, k = C.c_double(), C.c_double(), C.c_int()
+        check(lib().pqps_ctx_kernel_time(self.h, C.byref(ev), C.byref(tot), C.byref(k)))
+        return ev.value, tot.value, k.value
 
     def close(self):
         if self.h:

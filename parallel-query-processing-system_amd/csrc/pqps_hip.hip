@@ -1,35 +1,9 @@
 // pqps_hip.hip -- gfx950 (MI355X, CDNA4) kernels + the C-ABI shim of include/pqps_hip.h.
 //
-// The ONLY translation unit compiled by hipcc.  No CUDA-compat headers, no
-// dual paths: wave = 64 lanes, written for CDNA4 directly.
-//
-// Hot kernel: filter_kernel<MODE, GATHER>
-//   replaces linearSearchRecords + evaluateWhereClause + checkCondition + CMP_*
-//   of the reference (engine/serial/executeEngine-serial.c:854-878, :292-316,
-//   :251-289, :18-123) with one single-pass, order-preserving, HBM-bound scan:
-//
-//   * columns are separate device arrays (SoA); a 256-thread workgroup owns a
-//     tile of 4096 rows; wave w owns 1024 contiguous rows as 4 chunks of 256;
-//     lane l owns rows 4l..4l+3 of each chunk => every 4-byte column is read
-//     with one fully coalesced global_load_dwordx4 per chunk (1 KiB / wave
-//     instruction), 1-byte columns with a dword, 2-byte with dwordx2, 8-byte
-//     with two dwordx4.  Each predicate column is read exactly once.
-//   * predicate operands (window lo/span per leaf) are staged in LDS once per
-//     workgroup; every leaf is the unsigned window test ((x - lo) <= span) ^ neg;
-//     the boolean tree is a 64-entry truth table (<= 6 leaves) or a jump table.
-//   * stream compaction: per chunk three __ballot()s of the per-lane match
-//     count bits + mbcnt give the exclusive lane prefix; wave totals meet in
-//     LDS; tile totals are chained across workgroups by a decoupled look-back
-//     over 8-byte {flag,value} status words (relaxed agent-scope atomics: the
-//     value IS the flag, so no separate payload / fence is needed); row IDs are
-//     written in ascending order exactly once.
-//   * persistent grid: G = min(tiles, CUs * BLOCKS_PER_CU) workgroups, tile t
-//     handled by block t % G in increasing order.  All G blocks are co-resident
-//     (BLOCKS_PER_CU is half of what the register/LDS budget admits), so every
-//     predecessor a look-back waits for is running; spins are bounded and set
-//     an error word instead of hanging.
-//
+// The ONLY translation unit compiled by hipcc (filter_kernels.hpp is included here).
+// No CUDA-compat headers, no dual paths: wave = 64 lanes, written for CDNA4 directly.
 // No MFMA anywhere: this is integer compare + compaction, bound by HBM reads.
+// The filter pipeline (K1 eval -> K2 scan -> K3 expand) is described in filter_kernels.hpp.
 
 #include <cmath>
 #include <cstdarg>
@@ -37,379 +11,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>   // index build only (stable LSD sort)
 
 #include "pqps_hip.h"
+#include "filter_kernels.hpp"
 
 namespace {
-
-constexpr int kBlock = 256;                 // threads per workgroup (4 waves)
-constexpr int kWaves = kBlock / 64;
-constexpr int kChunksPerWave = 4;           // 4 x 256 rows per wave per tile
-constexpr int kRowsPerLane = 4;             // consecutive rows per lane per chunk
-constexpr int kChunkRows = 64 * kRowsPerLane;                       // 256
-constexpr int kTileRows = kWaves * kChunksPerWave * kChunkRows;     // 4096
-static_assert(kTileRows == PQPS_TILE_ROWS, "tile size is part of the ABI");
-constexpr int kBlocksPerCU = 4;
-
-enum Mode { MODE_IDS = 0, MODE_COUNT = 1, MODE_FLAGS = 2 };
-
-// status word of one tile: [63:62] flag, [61:0] value
-constexpr uint64_t kFlagAgg = 1ull << 62;      // value = matches of this tile
-constexpr uint64_t kFlagPrefix = 2ull << 62;   // value = matches of tiles 0..this
-constexpr uint64_t kValueMask = (1ull << 62) - 1;
-constexpr uint32_t kSpinLimit = 1u << 22;      // bounded look-back spin
-
-// scratch header (8 x u64) in front of the status array
-enum { HDR_ERROR = 0, HDR_TOTAL = 1, HDR_WORDS = 8 };
-
-struct FilterArgs {
-    const void *col[PQPS_MAX_COLUMNS];
-    uint64_t lo[PQPS_MAX_LEAVES];
-    uint64_t span[PQPS_MAX_LEAVES];
-    uint64_t truth;
-    uint64_t n_rows;            // scan: rows; gather: upper bound only (range read on device)
-    uint64_t out_cap;
-    uint32_t *out_ids;
-    uint8_t *out_flags;
-    uint64_t *out_count;        // device
-    uint64_t *scratch;          // header + status[]
-    const uint32_t *cand;       // gather: candidate row numbers
-    const uint64_t *range;      // gather: [begin, end) into cand, device
-    uint32_t id_base;
-    uint32_t n_cols;
-    uint32_t n_leaves;
-    uint32_t negmask;
-    uint8_t width_log2[PQPS_MAX_COLUMNS];
-    uint8_t leaf_begin[PQPS_MAX_COLUMNS + 1];   // leaves of column c: [leaf_begin[c], leaf_begin[c+1])
-    uint8_t on_true[PQPS_MAX_LEAVES];
-    uint8_t on_false[PQPS_MAX_LEAVES];
-    uint8_t order[PQPS_MAX_LEAVES];
-};
-
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-
-// exclusive count of set bits of `mask` below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ uint64_t status_load(const uint64_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void status_store(uint64_t *p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One value of a column at an arbitrary row (partial tiles, gather mode).
-__device__ __forceinline__ uint64_t load_one(const void *base, int wlog2, uint64_t row) {
-    switch (wlog2) {
-    case 0: return ((const uint8_t *)base)[row];
-    case 1: return ((const uint16_t *)base)[row];
-    case 2: return ((const uint32_t *)base)[row];
-    default: return ((const uint64_t *)base)[row];
-    }
-}
-
-// Decoupled look-back executed by wave 0 of the workgroup that owns `tile`.
-// Returns the number of matches in tiles [0, tile).  `total` = matches of this tile.
-__device__ __forceinline__ uint64_t lookback(uint64_t *scratch, uint64_t tile, uint64_t total) {
-    uint64_t *status = scratch + HDR_WORDS;
-    const uint32_t lane = lane_id();
-    if (tile == 0) {
-        if (lane == 0) status_store(&status[0], kFlagPrefix | total);
-        return 0;
-    }
-    if (lane == 0) status_store(&status[tile], kFlagAgg | total);
-    uint64_t excl = 0;
-    int64_t look = (int64_t)tile - 1;
-    uint32_t spins = 0;
-    while (true) {
-        const int64_t t = look - (int64_t)lane;
-        // tiles before 0: a virtual "prefix = 0"
-        const uint64_t s = (t >= 0) ? status_load(&status[t]) : kFlagPrefix;
-        const uint32_t flag = (uint32_t)(s >> 62);
-        const uint64_t ready = __ballot(flag != 0);
-        const uint64_t isprefix = __ballot(flag == 2);
-        const int p = isprefix ? __builtin_ctzll(isprefix) : 64;     // nearest inclusive prefix
-        const uint64_t need = (p >= 63) ? ~0ull : ((2ull << p) - 1);
-        if ((ready & need) != need) {
-            if (++spins > kSpinLimit) {                                // never hang the GPU
-                if (lane == 0) atomicExch((unsigned long long *)&scratch[HDR_ERROR], 1ull);
-                return excl;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        const uint64_t v = ((int)lane <= p) ? (s & kValueMask) : 0;
-        excl += wave_sum_u64(v);
-        if (p != 64) break;
-        look -= 64;
-    }
-    if (lane == 0) status_store(&status[tile], kFlagPrefix | (excl + total));
-    return excl;
-}
-
-template <int MODE, bool GATHER>
-__global__ __launch_bounds__(kBlock, kBlocksPerCU)
-void filter_kernel(const FilterArgs a) {
-    // LDS-staged predicate operands + compaction scratch
-    __shared__ uint64_t s_lo[PQPS_MAX_LEAVES];
-    __shared__ uint64_t s_span[PQPS_MAX_LEAVES];
-    __shared__ uint32_t s_wave_total[kWaves];
-    __shared__ uint64_t s_tile_excl;
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63;
-    const uint32_t wave = tid >> 6;
-
-    if (tid < PQPS_MAX_LEAVES) {
-        s_lo[tid] = a.lo[tid];
-        s_span[tid] = a.span[tid];
-    }
-    __syncthreads();
-
-    uint64_t begin = 0, n_rows = a.n_rows;
-    if (GATHER) {
-        begin = a.range[0];
-        const uint64_t end = a.range[1];
-        n_rows = end > begin ? end - begin : 0;
-        if (n_rows > a.n_rows) n_rows = a.n_rows;     // never past the caller's bound
-    }
-    const uint64_t num_tiles = (n_rows + kTileRows - 1) / kTileRows;
-    const uint64_t out_base = (GATHER && MODE == MODE_IDS) ? *a.out_count : 0;
-
-    uint64_t block_count = 0;      // MODE_COUNT / MODE_FLAGS accumulate locally
-
-    for (uint64_t tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-        const uint64_t tile_row0 = tile * kTileRows;
-        const uint64_t wave_row0 = tile_row0 + (uint64_t)wave * (kChunksPerWave * kChunkRows);
-        const bool full = !GATHER && (tile_row0 + kTileRows <= n_rows);
-
-        // per row: bit k = result of leaf k
-        uint32_t idx[kChunksPerWave][kRowsPerLane];
-#pragma unroll
-        for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-            for (int j = 0; j < kRowsPerLane; j++) idx[u][j] = 0;
-
-        // gather mode / partial tiles: resolve row numbers once
-        uint64_t rowno[kChunksPerWave][kRowsPerLane];
-        if (!full) {
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                for (int j = 0; j < kRowsPerLane; j++) {
-                    const uint64_t pos = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane + j;
-                    uint64_t r = ~0ull;
-                    if (pos < n_rows) r = GATHER ? (uint64_t)a.cand[begin + pos] : pos;
-                    rowno[u][j] = r;
-                }
-        }
-
-        for (uint32_t c = 0; c < a.n_cols; c++) {             // uniform
-            const char *base = (const char *)a.col[c];
-            const int wl = a.width_log2[c];
-            const uint32_t kb = a.leaf_begin[c], ke = a.leaf_begin[c + 1];
-            if (wl == 3) {
-                uint64_t v[kChunksPerWave][kRowsPerLane];
-                if (full) {
-#pragma unroll
-                    for (int u = 0; u < kChunksPerWave; u++) {
-                        const uint64_t r0 = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane;
-                        const uint4 q0 = *(const uint4 *)(base + r0 * 8);
-                        const uint4 q1 = *(const uint4 *)(base + r0 * 8 + 16);
-                        v[u][0] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
-                        v[u][1] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
-                        v[u][2] = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
-                        v[u][3] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                        for (int j = 0; j < kRowsPerLane; j++)
-                            v[u][j] = rowno[u][j] != ~0ull ? load_one(base, 3, rowno[u][j]) : 0;
-                }
-                for (uint32_t k = kb; k < ke; k++) {            // uniform
-                    const uint64_t lo = s_lo[k], span = s_span[k];
-                    const uint32_t neg = (a.negmask >> k) & 1u, bit = 1u << k;
-#pragma unroll
-                    for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                        for (int j = 0; j < kRowsPerLane; j++) {
-                            const uint32_t hit = ((v[u][j] - lo) <= span) ? 1u : 0u;
-                            idx[u][j] |= (hit ^ neg) ? bit : 0u;
-                        }
-                }
-            } else {
-                uint32_t v[kChunksPerWave][kRowsPerLane];
-                if (full) {
-                    if (wl == 2) {
-#pragma unroll
-                        for (int u = 0; u < kChunksPerWave; u++) {
-                            const uint64_t r0 = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane;
-                            const uint4 q = *(const uint4 *)(base + r0 * 4);
-                            v[u][0] = q.x; v[u][1] = q.y; v[u][2] = q.z; v[u][3] = q.w;
-                        }
-                    } else if (wl == 1) {
-#pragma unroll
-                        for (int u = 0; u < kChunksPerWave; u++) {
-                            const uint64_t r0 = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane;
-                            const uint2 q = *(const uint2 *)(base + r0 * 2);
-                            v[u][0] = q.x & 0xFFFFu; v[u][1] = q.x >> 16;
-                            v[u][2] = q.y & 0xFFFFu; v[u][3] = q.y >> 16;
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < kChunksPerWave; u++) {
-                            const uint64_t r0 = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane;
-                            const uint32_t q = *(const uint32_t *)(base + r0);
-                            v[u][0] = q & 0xFFu; v[u][1] = (q >> 8) & 0xFFu;
-                            v[u][2] = (q >> 16) & 0xFFu; v[u][3] = q >> 24;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                        for (int j = 0; j < kRowsPerLane; j++)
-                            v[u][j] = rowno[u][j] != ~0ull ? (uint32_t)load_one(base, wl, rowno[u][j]) : 0u;
-                }
-                for (uint32_t k = kb; k < ke; k++) {            // uniform
-                    const uint32_t lo = (uint32_t)s_lo[k], span = (uint32_t)s_span[k];
-                    const uint32_t neg = (a.negmask >> k) & 1u, bit = 1u << k;
-#pragma unroll
-                    for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                        for (int j = 0; j < kRowsPerLane; j++) {
-                            const uint32_t hit = ((v[u][j] - lo) <= span) ? 1u : 0u;
-                            idx[u][j] |= (hit ^ neg) ? bit : 0u;
-                        }
-                }
-            }
-        }
-
-        // boolean tree -> one match bit per row; bit (4u+j) of mbits
-        uint32_t mbits = 0;
-        if (a.n_leaves <= PQPS_TT_LEAVES) {
-            const uint64_t tt = a.truth;
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                for (int j = 0; j < kRowsPerLane; j++)
-                    mbits |= ((uint32_t)(tt >> idx[u][j]) & 1u) << (u * kRowsPerLane + j);
-        } else {
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                for (int j = 0; j < kRowsPerLane; j++) {
-                    uint32_t state = 0;                         // step index, ACCEPT or REJECT
-                    for (uint32_t s = 0; s < a.n_leaves; s++) {   // uniform bound
-                        const uint32_t r = (idx[u][j] >> a.order[s]) & 1u;
-                        const uint32_t nxt = r ? a.on_true[s] : a.on_false[s];
-                        state = (state == s) ? nxt : state;
-                    }
-                    mbits |= (state == PQPS_ACCEPT ? 1u : 0u) << (u * kRowsPerLane + j);
-                }
-        }
-        // rows past the end of a partial tile never match
-        if (!full) {
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++)
-#pragma unroll
-                for (int j = 0; j < kRowsPerLane; j++)
-                    if (rowno[u][j] == ~0ull) mbits &= ~(1u << (u * kRowsPerLane + j));
-        }
-
-        if (MODE == MODE_FLAGS) {
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++) {
-                const uint64_t r0 = wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane;
-                const uint32_t m4 = (mbits >> (u * kRowsPerLane)) & 0xFu;
-                const uint32_t packed = (m4 & 1u) | ((m4 & 2u) << 7) | ((m4 & 4u) << 14) | ((m4 & 8u) << 21);
-                if (r0 + kRowsPerLane <= n_rows) {
-                    *(uint32_t *)(a.out_flags + r0) = packed;
-                } else {
-                    for (int j = 0; j < kRowsPerLane; j++)
-                        if (r0 + j < n_rows) a.out_flags[r0 + j] = (uint8_t)((m4 >> j) & 1u);
-                }
-            }
-        }
-        if (MODE != MODE_IDS) {
-            block_count += __popc(mbits);
-            continue;
-        }
-
-        // ---- order-preserving compaction -----------------------------------
-        // lane prefix inside each chunk via ballots of the 3 count bits
-        uint32_t lane_off[kChunksPerWave];
-        uint32_t wave_total = 0;
-#pragma unroll
-        for (int u = 0; u < kChunksPerWave; u++) {
-            const uint32_t cnt = __popc((mbits >> (u * kRowsPerLane)) & 0xFu);    // 0..4
-            const uint64_t b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
-            lane_off[u] = wave_total + mbcnt(b0) + 2u * mbcnt(b1) + 4u * mbcnt(b2);
-            wave_total += (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-        }
-        if (lane == 0) s_wave_total[wave] = wave_total;
-        __syncthreads();
-        uint32_t wave_off = 0, tile_total = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; w++) {
-            const uint32_t t = s_wave_total[w];
-            wave_off += (w < (int)wave) ? t : 0u;
-            tile_total += t;
-        }
-        if (wave == 0) {
-            const uint64_t excl = lookback(a.scratch, tile, tile_total);
-            if (lane == 0) {
-                s_tile_excl = excl;
-                if (tile + 1 == num_tiles) a.scratch[HDR_TOTAL] = excl + tile_total;
-            }
-        }
-        __syncthreads();
-        const uint64_t tile_excl = s_tile_excl;
-        if (mbits) {
-#pragma unroll
-            for (int u = 0; u < kChunksPerWave; u++) {
-                uint64_t pos = out_base + tile_excl + wave_off + lane_off[u];
-#pragma unroll
-                for (int j = 0; j < kRowsPerLane; j++) {
-                    if (mbits & (1u << (u * kRowsPerLane + j))) {
-                        uint32_t id;
-                        if (full) id = (uint32_t)(wave_row0 + (uint64_t)u * kChunkRows + lane * kRowsPerLane + j);
-                        else id = (uint32_t)rowno[u][j];
-                        if (pos < a.out_cap) a.out_ids[pos] = id + a.id_base;
-                        pos++;
-                    }
-                }
-            }
-        }
-        // s_wave_total / s_tile_excl are rewritten only after the next tile's
-        // first barrier, which every thread reaches after reading them here.
-    }
-
-    if (MODE != MODE_IDS) {
-        const uint64_t w = wave_sum_u64(block_count);
-        if (lane == 0 && w) atomicAdd((unsigned long long *)a.out_count, (unsigned long long)w);
-    }
-}
-
-// Scan mode: the last tile's owner left the total in the header; publish it.
-__global__ void finish_kernel(uint64_t *scratch, uint64_t *out_count, int accumulate) {
-    const uint64_t total = scratch[HDR_TOTAL];
-    if (accumulate) *out_count += total; else *out_count = total;
-}
 
 // ---- index build / probe ---------------------------------------------------
 template <typename K>
@@ -573,27 +183,42 @@ struct pqps_ctx {
     int device;
     int compute_units;
     hipStream_t stream;
-    uint64_t *scratch;          // HDR_WORDS + status words
-    uint64_t scratch_words;
+    // filter scratch, grown on demand: match bits, step counts, group sums / offsets, ticket
+    uint64_t scratch_steps;     // capacity in steps of 1024 rows
+    uint16_t *masks;
+    uint32_t *counts;
+    uint64_t *group_sum, *group_excl;
+    uint32_t *ticket;
     void *sort_tmp;
     size_t sort_tmp_bytes;
-    // optional per-launch timing of the filter kernel (bench.py roofline)
+    // optional per-launch timing (bench.py roofline): K1 alone and K1..K3
     bool timing;
     int timed;                  // launches recorded since the last reset
-    hipEvent_t *ev_start, *ev_stop;
+    hipEvent_t *ev_start, *ev_eval, *ev_stop;
 };
 
 namespace {
 
 hipStream_t pick_stream(pqps_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
-int ensure_scratch(pqps_ctx *ctx, uint64_t tiles) {
-    const uint64_t need = HDR_WORDS + tiles + 64;
-    if (ctx->scratch_words >= need) return PQPS_OK;
-    if (ctx->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_words = 0; }
-    const uint64_t words = need + need / 2;
-    HIP_TRY(hipMalloc((void **)&ctx->scratch, words * sizeof(uint64_t)));
-    ctx->scratch_words = words;
+int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
+    if (ctx->scratch_steps >= steps && ctx->masks) return PQPS_OK;
+    if (ctx->masks) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(ctx->masks); (void)hipFree(ctx->counts); (void)hipFree(ctx->group_sum);
+        (void)hipFree(ctx->group_excl); (void)hipFree(ctx->ticket);
+        ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = ctx->group_excl = nullptr; ctx->ticket = nullptr;
+        ctx->scratch_steps = 0;
+    }
+    const uint64_t cap = steps + steps / 4 + 64;
+    const uint64_t groups = (cap + kGroupSteps - 1) / kGroupSteps;
+    HIP_TRY(hipMalloc((void **)&ctx->masks, cap * 64 * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->group_sum, groups * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->group_excl, groups * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->ticket, 64));
+    HIP_TRY(hipMemset(ctx->ticket, 0, 64));
+    ctx->scratch_steps = cap;
     return PQPS_OK;
 }
 
@@ -626,7 +251,7 @@ int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *p
     return PQPS_OK;
 }
 
-void fill_args(FilterArgs &a, const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
+void fill_args(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
     memset(&a, 0, sizeof a);
     a.n_cols = n_cols;
     a.n_leaves = pred->n_leaves;
@@ -651,24 +276,75 @@ void fill_args(FilterArgs &a, const pqps_column *cols, uint32_t n_cols, const pq
     }
 }
 
-uint32_t grid_for(pqps_ctx *ctx, uint64_t tiles) {
-    const uint64_t cap = (uint64_t)ctx->compute_units * kBlocksPerCU;
-    const uint64_t g = tiles < cap ? tiles : cap;
+// ---- K1 dispatch: width-specialised instantiations ----------------------------------------
+typedef void (*eval_fn)(const EvalArgs);
+
+// every non-increasing (W0, W1, W2) from {8,4,2,1}, W = 0 marks an unused slot
+#define PQPS_FOR_EACH_SHAPE(X) \
+    X(8,0,0) X(4,0,0) X(2,0,0) X(1,0,0) \
+    X(8,8,0) X(8,4,0) X(8,2,0) X(8,1,0) X(4,4,0) X(4,2,0) X(4,1,0) X(2,2,0) X(2,1,0) X(1,1,0) \
+    X(8,8,8) X(8,8,4) X(8,8,2) X(8,8,1) X(8,4,4) X(8,4,2) X(8,4,1) X(8,2,2) X(8,2,1) X(8,1,1) \
+    X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
+
+template <int MODE>
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2) {
+#define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return eval_spec_kernel<MODE, A, B, C>;
+    PQPS_FOR_EACH_SHAPE(X)
+#undef X
+    return nullptr;
+}
+
+template <int MODE>
+eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
+    if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1) {
+        const uint32_t w0 = cols[0].width, w1 = n_cols > 1 ? cols[1].width : 0, w2 = n_cols > 2 ? cols[2].width : 0;
+        if (eval_fn f = find_spec<MODE>(w0, w1, w2)) return f;      // nullptr unless widths are non-increasing
+    }
+    return eval_generic_kernel<MODE, false>;
+}
+
+uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps) {
+    const uint64_t want = (steps + kWaves - 1) / kWaves;
+    const uint64_t cap = (uint64_t)ctx->compute_units * 16;
+    const uint64_t g = want < cap ? want : cap;
     return (uint32_t)(g ? g : 1);
 }
 
-template <int MODE, bool GATHER>
-int launch_filter(pqps_ctx *ctx, FilterArgs &a, uint64_t tiles, hipStream_t s) {
-    int rc = ensure_scratch(ctx, tiles);
+// K1 (+ K2 + K3 for ID output).  `rows` = scan rows or the gather upper bound.
+int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
+               uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s) {
+    const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
+    int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
-    a.scratch = ctx->scratch;
-    // zero header + status words this launch can touch (16-byte multiple from the allocation start)
-    const size_t zero_bytes = ((HDR_WORDS + tiles) * sizeof(uint64_t) + 15) & ~(size_t)15;
-    HIP_TRY(hipMemsetAsync(ctx->scratch, 0, zero_bytes, s));
+    a.masks = ctx->masks;
+    a.counts = ctx->counts;
+    a.out_count = (unsigned long long *)out_count;
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev_start[ctx->timed], s));
-    hipLaunchKernelGGL((filter_kernel<MODE, GATHER>), dim3(grid_for(ctx, tiles)), dim3(kBlock), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    if (steps) {
+        hipLaunchKernelGGL(k1, dim3(eval_grid(ctx, steps)), dim3(kBlock), 0, s, a);
+        HIP_TRY(hipGetLastError());
+    }
+    if (timed) HIP_TRY(hipEventRecord(ctx->ev_eval[ctx->timed], s));
+    if (mode == MODE_IDS) {
+        const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+        ScanArgs sa;
+        sa.counts = ctx->counts; sa.steps = steps; sa.groups = groups;
+        sa.group_sum = ctx->group_sum; sa.group_excl = ctx->group_excl; sa.ticket = ctx->ticket;
+        sa.out_count = out_count; sa.accumulate = gather ? 1 : 0;
+        const uint32_t scan_blocks = (uint32_t)((groups + kWaves - 1) / kWaves);
+        hipLaunchKernelGGL(scan_kernel, dim3(scan_blocks ? scan_blocks : 1), dim3(kBlock), 0, s, sa);
+        HIP_TRY(hipGetLastError());
+        if (groups) {
+            ExpandArgs ea;
+            ea.masks = ctx->masks; ea.counts = ctx->counts; ea.group_excl = ctx->group_excl;
+            ea.steps = steps; ea.groups = groups; ea.out_ids = out_ids; ea.out_cap = out_cap;
+            ea.cand = a.cand; ea.range = a.range; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
+            const uint64_t want = (groups + kWaves - 1) / kWaves, cap = (uint64_t)ctx->compute_units * 8;
+            hipLaunchKernelGGL(expand_kernel, dim3((uint32_t)(want < cap ? want : cap)), dim3(kBlock), 0, s, ea);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     if (timed) { HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
     return PQPS_OK;
 }
@@ -701,13 +377,13 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     if (!ctx) return fail(PQPS_ENOMEM, "out of host memory");
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
-    ctx->scratch = nullptr;
-    ctx->scratch_words = 0;
+    ctx->scratch_steps = 0;
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = ctx->group_excl = nullptr; ctx->ticket = nullptr;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
     ctx->timed = 0;
-    ctx->ev_start = ctx->ev_stop = nullptr;
+    ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete ctx; return fail(PQPS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     *out = ctx;
@@ -718,11 +394,17 @@ void pqps_ctx_destroy(pqps_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->masks) {
+        (void)hipFree(ctx->masks); (void)hipFree(ctx->counts); (void)hipFree(ctx->group_sum);
+        (void)hipFree(ctx->group_excl); (void)hipFree(ctx->ticket);
+    }
     if (ctx->sort_tmp) (void)hipFree(ctx->sort_tmp);
     if (ctx->ev_start) {
-        for (int i = 0; i < kMaxTimedLaunches; i++) { (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_stop[i]); }
+        for (int i = 0; i < kMaxTimedLaunches; i++) {
+            (void)hipEventDestroy(ctx->ev_start[i]); (void)hipEventDestroy(ctx->ev_eval[i]); (void)hipEventDestroy(ctx->ev_stop[i]);
+        }
         delete[] ctx->ev_start;
+        delete[] ctx->ev_eval;
         delete[] ctx->ev_stop;
     }
     (void)hipStreamDestroy(ctx->stream);
@@ -733,10 +415,12 @@ int pqps_ctx_set_timing(pqps_ctx *ctx, int enable) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
     if (enable && !ctx->ev_start) {
         ctx->ev_start = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
+        ctx->ev_eval = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
         ctx->ev_stop = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
-        if (!ctx->ev_start || !ctx->ev_stop) return fail(PQPS_ENOMEM, "out of host memory");
+        if (!ctx->ev_start || !ctx->ev_eval || !ctx->ev_stop) return fail(PQPS_ENOMEM, "out of host memory");
         for (int i = 0; i < kMaxTimedLaunches; i++) {
             HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
+            HIP_TRY(hipEventCreate(&ctx->ev_eval[i]));
             HIP_TRY(hipEventCreate(&ctx->ev_stop[i]));
         }
     }
@@ -745,16 +429,19 @@ int pqps_ctx_set_timing(pqps_ctx *ctx, int enable) {
     return PQPS_OK;
 }
 
-int pqps_ctx_kernel_time(pqps_ctx *ctx, double *total_ms, int *launches) {
-    if (!ctx || !total_ms || !launches) return fail(PQPS_EINVAL, "NULL argument");
-    double sum = 0.0;
+int pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *launches) {
+    if (!ctx || !eval_ms || !total_ms || !launches) return fail(PQPS_EINVAL, "NULL argument");
+    double sum_eval = 0.0, sum_total = 0.0;
     for (int i = 0; i < ctx->timed; i++) {
         HIP_TRY(hipEventSynchronize(ctx->ev_stop[i]));
         float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_eval[i]));
+        sum_eval += ms;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
-        sum += ms;
+        sum_total += ms;
     }
-    *total_ms = sum;
+    *eval_ms = sum_eval;
+    *total_ms = sum_total;
     *launches = ctx->timed;
     ctx->timed = 0;
     return PQPS_OK;
@@ -763,11 +450,6 @@ int pqps_ctx_kernel_time(pqps_ctx *ctx, double *total_ms, int *launches) {
 int pqps_ctx_sync(pqps_ctx *ctx, void *stream) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(pick_stream(ctx, stream)));
-    if (ctx->scratch) {
-        uint64_t err = 0;
-        HIP_TRY(hipMemcpy(&err, ctx->scratch + HDR_ERROR, sizeof err, hipMemcpyDeviceToHost));
-        if (err) return fail(PQPS_EHIP, "look-back spin limit hit: results of the last filter are invalid");
-    }
     return PQPS_OK;
 }
 
@@ -826,20 +508,11 @@ int pqps_filter_scan(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
         return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
-    hipStream_t s = pick_stream(ctx, stream);
-    FilterArgs a;
+    EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    a.id_base = id_base;
-    a.out_ids = out_ids;
-    a.out_cap = out_capacity;
-    a.out_count = out_count;
-    const uint64_t tiles = (n_rows + kTileRows - 1) / kTileRows;
-    rc = launch_filter<MODE_IDS, false>(ctx, a, tiles, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1), 0, s, ctx->scratch, out_count, 0);
-    HIP_TRY(hipGetLastError());
-    return PQPS_OK;
+    return run_filter(ctx, pick_eval<MODE_IDS>(cols, n_cols, pred), a, n_rows, MODE_IDS, false,
+                      id_base, out_ids, out_capacity, out_count, pick_stream(ctx, stream));
 }
 
 int pqps_filter_count(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
@@ -848,31 +521,28 @@ int pqps_filter_count(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
     hipStream_t s = pick_stream(ctx, stream);
-    FilterArgs a;
+    EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    a.out_count = out_count;
     HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
-    const uint64_t tiles = (n_rows + kTileRows - 1) / kTileRows;
-    return launch_filter<MODE_COUNT, false>(ctx, a, tiles, s);
+    return run_filter(ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred), a, n_rows, MODE_COUNT, false,
+                      0, nullptr, 0, out_count, s);
 }
 
 int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
                       uint64_t n_rows, const pqps_predicate *pred,
                       uint8_t *out_flags, uint64_t *out_count, void *stream) {
     if (!ctx || !out_count || !out_flags) return fail(PQPS_EINVAL, "ctx/out_flags/out_count is NULL");
-    if (((uintptr_t)out_flags & 3u) != 0) return fail(PQPS_EINVAL, "out_flags must be 4-byte aligned");
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
     hipStream_t s = pick_stream(ctx, stream);
-    FilterArgs a;
+    EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
     a.out_flags = out_flags;
-    a.out_count = out_count;
     HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
-    const uint64_t tiles = (n_rows + kTileRows - 1) / kTileRows;
-    return launch_filter<MODE_FLAGS, false>(ctx, a, tiles, s);
+    return run_filter(ctx, eval_generic_kernel<MODE_FLAGS, false>, a, n_rows, MODE_FLAGS, false,
+                      0, nullptr, 0, out_count, s);
 }
 
 int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
@@ -883,22 +553,13 @@ int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
-    hipStream_t s = pick_stream(ctx, stream);
-    FilterArgs a;
+    EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = max_candidates;
-    a.id_base = id_base;
     a.cand = cand;
     a.range = range;
-    a.out_ids = out_ids;
-    a.out_cap = out_capacity;
-    a.out_count = out_count;
-    const uint64_t tiles = (max_candidates + kTileRows - 1) / kTileRows;
-    rc = launch_filter<MODE_IDS, true>(ctx, a, tiles, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1), 0, s, ctx->scratch, out_count, 1);
-    HIP_TRY(hipGetLastError());
-    return PQPS_OK;
+    return run_filter(ctx, eval_generic_kernel<MODE_IDS, true>, a, max_candidates, MODE_IDS, true,
+                      id_base, out_ids, out_capacity, out_count, pick_stream(ctx, stream));
 }
 
 }  // extern "C"

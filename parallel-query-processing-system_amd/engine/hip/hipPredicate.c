@@ -236,12 +236,19 @@ int hipCompileWhere(const struct hipSchema *schema, const struct whereClauseS *w
         return -1;
     }
 
-    /* column slots: distinct columns of the reachable leaves, ascending HIPCOL id */
+    /* column slots: distinct columns of the reachable leaves, widest first (then
+     * ascending HIPCOL id) -- the order the width-specialised kernels expect */
     int cols[PQPS_MAX_LEAVES], nc = 0;
     for (int s = 0; s < raw; s++) if (reach[s]) cols[nc++] = b->st[s].col;
     qsort(cols, (size_t)nc, sizeof cols[0], cmp_int);
     int n_cols = 0;
     for (int i = 0; i < nc; i++) if (i == 0 || cols[i] != cols[i - 1]) column_ids[n_cols++] = cols[i];
+    for (int i = 1; i < n_cols; i++) {                           /* stable insertion sort by width desc */
+        const int c = column_ids[i];
+        int j = i;
+        while (j > 0 && schema->col[column_ids[j - 1]].width < schema->col[c].width) { column_ids[j] = column_ids[j - 1]; j--; }
+        column_ids[j] = c;
+    }
 
     /* leaf slots sorted by column slot (stable in evaluation order) */
     int slot_of_step[PQPS_MAX_LEAVES];
