@@ -233,15 +233,22 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
-    ctx.set_timing(True)
+    # ---- timed region: exactly K steps, nothing but the hot path (+ merge) enqueued -------
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     fence()
     elapsed = time.perf_counter() - t0
+    # ---- same K steps again with HIP events around every launch of the evaluate kernel (the
+    # only kernel that reads the table) on its own stream: its average duration feeds
+    # `roofline`.  Kept out of the timed region because an event record costs a few us of
+    # queue time per launch and would distort `value`.
+    ctx.set_timing(True)
+    for k in range(args.steps):
+        step(k)
+    fence()
     kern_ms, pipe_ms, launches = ctx.kernel_time()
     ctx.set_timing(False)
-    ctx.sync(sptr)                                       # also surfaces a look-back timeout
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -5,7 +5,7 @@
 // with three stream-ordered kernels, none of which ever waits on another workgroup:
 //
 //  K1 eval    one wave = one STEP of 1024 consecutive rows (16 rows per lane); grid-stride
-//             over steps, no LDS, no barriers.  Lane l owns RPL = 16/Wmax consecutive rows
+//             over steps, no LDS, no barriers.  Lane l owns RPL = 16/Wmax (4 for 8-byte) consecutive rows
 //             of each 64*RPL-row chunk, so the widest predicate column is read with ONE fully
 //             coalesced global_load_dwordx4 per chunk and narrower ones with dwordx2 / dword /
 //             ushort loads that are just as contiguous across the wave.  Every predicate
@@ -13,10 +13,12 @@
 //             ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth table (<= 6
 //             leaves) or a jump table.  Output per step: 16 match bits per lane (one coalesced
 //             128-byte store, skipped when the step has no match) + the step's match count.
-//  K2 scan    per 64 steps a wave sums the counts; the last workgroup to finish scans those
-//             sums (threadfence + ticket) -> exclusive offset of every 64-step group + total.
-//  K3 expand  wave per group: wave-prefix of the 64 step counts, then for every non-empty step
-//             the match bits become ascending row IDs (ballot + mbcnt lane prefix).
+//  K2 sums    per group of 64 steps a wave sums the counts; group sums are also added (one
+//             atomic per non-empty group) into supergroup sums of 64 groups.
+//  K3 expand  workgroup per group: its first output slot = supergroup sums before it + earlier
+//             group sums of its supergroup (a few hundred values, no serial scan); wave-prefix of
+//             the 64 step counts; for every non-empty step the match bits become ascending row
+//             IDs (ballot + mbcnt lane prefix).
 //
 // K1 dominates (it is the only kernel that touches the table) and is bound by HBM reads.
 // Width-specialised instantiations (1-3 predicate columns, widths non-increasing) keep all
@@ -42,7 +44,10 @@ struct EvalArgs {
     uint16_t *masks;                 // [steps][64] match bits of every lane
     uint32_t *counts;                // [steps]     matches | log2(RPL) << 28
     uint8_t *out_flags;              // MODE_FLAGS
-    unsigned long long *out_count;   // MODE_COUNT / MODE_FLAGS: device total
+    uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
+    unsigned long long *super_sum;   // MODE_IDS: [n_super] zeroed here for the K2 that follows
+    uint32_t n_super;
+    uint32_t pad1;
     const uint32_t *cand;            // gather: candidate row numbers
     const uint64_t *range;           // gather: [begin, end) into cand, device resident
     uint32_t n_cols;
@@ -64,10 +69,35 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// ---- wave-wide reductions on the DPP path (no LDS crossbar, ~6 VALU) ----------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    // lanes whose DPP source is invalid or masked receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// sum over the 64 lanes, returned in every lane
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_or_zero<0xb1>(v);                  // quad_perm [1,0,3,2]
+    v += dpp_or_zero<0x4e>(v);                  // quad_perm [2,3,0,1]
+    v += dpp_or_zero<0x124>(v);                 // row_ror:4
+    v += dpp_or_zero<0x128>(v);                 // row_ror:8   -> every lane holds its row total
+    v += dpp_or_zero<0x142, 0xa>(v);            // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);            // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
+    uint32_t t = x;
+    t += dpp_or_zero<0x111>(x);                 // row_shr:1
+    t += dpp_or_zero<0x112>(x);                 // row_shr:2
+    t += dpp_or_zero<0x113>(x);                 // row_shr:3   -> windows of 4
+    t += dpp_or_zero<0x114, 0xf, 0xe>(t);       // row_shr:4   -> windows of 8
+    t += dpp_or_zero<0x118, 0xf, 0xc>(t);       // row_shr:8   -> prefix inside each row of 16
+    t += dpp_or_zero<0x142, 0xa>(t);            // + total of the previous row (rows 1, 3)
+    t += dpp_or_zero<0x143, 0xc>(t);            // + lanes 0..31 (rows 2, 3)
+    return t;
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
@@ -142,6 +172,20 @@ __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint
                 if (row < n_rows) a.out_flags[row] = (uint8_t)((mbits >> p) & 1u);
             }
         }
+    }
+}
+
+// COUNT / FLAGS modes: one partial total per workgroup, summed by reduce_totals_kernel.
+template <int MODE>
+__device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_total) {
+    if (MODE == MODE_IDS) return;
+    __shared__ uint64_t s_tot[kWaves];
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int i = 0; i < kWaves; i++) t += s_tot[i];
+        a.partials[blockIdx.x] = t;
     }
 }
 
@@ -246,8 +290,16 @@ __device__ __forceinline__ uint32_t eval_step_guarded(const EvalArgs &a, uint64_
 }
 
 // Generic K1: any predicate; scan (full steps vectorised) or gather (always guarded).
+// K2 accumulates supergroup sums with atomics; the first workgroup of K1 clears them.
+template <int MODE>
+__device__ __forceinline__ void clear_super_sums(const EvalArgs &a) {
+    if (MODE == MODE_IDS && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < a.n_super; i += kBlock) a.super_sum[(uint64_t)i * 512] = 0ull;   // kSuperStride
+}
+
 template <int MODE, bool GATHER>
 __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) {
+    clear_super_sums<MODE>(a);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -268,18 +320,21 @@ __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) 
         else if (step_row0 < n_rows) mbits = eval_step_guarded<GATHER>(a, step_row0, n_rows, begin, lane);
         emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
     }
-    if (MODE != MODE_IDS && lane == 0 && wave_total) atomicAdd(a.out_count, (unsigned long long)wave_total);
+    finish_totals<MODE>(a, wave_total);
 }
 
 // ---- width-specialised K1 ---------------------------------------------------------------
 // Raw bytes of RPL consecutive rows of a W-byte column, as dwords.
 template <int W, int RPL>
 struct RawChunk {
-    static constexpr int kBytes = W * RPL;                      // 16, 8, 4 or 2
+    static constexpr int kBytes = W * RPL;                      // 32 (8-byte column), 16, 8 or 4
     static constexpr int kDwords = kBytes >= 4 ? kBytes / 4 : 1;
     uint32_t d[kDwords];
     __device__ __forceinline__ void load(const char *p) {
-        if constexpr (kBytes == 16) { const uint4 q = *(const uint4 *)p; d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; }
+        if constexpr (kBytes == 32) {
+            const uint4 q = *(const uint4 *)p, r = *(const uint4 *)(p + 16);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; d[4] = r.x; d[5] = r.y; d[6] = r.z; d[7] = r.w;
+        } else if constexpr (kBytes == 16) { const uint4 q = *(const uint4 *)p; d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; }
         else if constexpr (kBytes == 8) { const uint2 q = *(const uint2 *)p; d[0] = q.x; d[1] = q.y; }
         else if constexpr (kBytes == 4) { d[0] = *(const uint32_t *)p; }
         else { d[0] = *(const uint16_t *)p; }
@@ -331,8 +386,11 @@ constexpr int log2i(int x) { return x <= 1 ? 0 : 1 + log2i(x / 2); }
 // W0 >= W1 >= W2 are the byte widths of the predicate columns (0 = slot unused).
 template <int MODE, int W0, int W1, int W2>
 __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
-    constexpr int RPL = 16 / W0;                                // consecutive rows per lane per chunk
+    // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
+    // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
+    constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;                                 // chunks per step
+    clear_super_sums<MODE>(a);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -363,57 +421,54 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
         const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
         emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
     }
-    if (MODE != MODE_IDS && lane == 0 && wave_total) atomicAdd(a.out_count, (unsigned long long)wave_total);
+    finish_totals<MODE>(a, wave_total);
 }
 
-// ---- K2: group sums + scan by the last workgroup ------------------------------------------
-struct ScanArgs {
+// ---- K2: group sums ---------------------------------------------------------------------
+// group = 64 steps (64 K rows); supergroup = 64 groups (4 M rows).
+constexpr int kSuperGroups = 64;
+// Device atomics that hit one cache line serialise (~5 ns each, measured), so every
+// supergroup counter lives in its own 4 KiB slot.
+constexpr int kSuperStride = 512;           // in u64
+
+struct SumArgs {
     const uint32_t *counts;          // [steps]
     uint64_t steps;
     uint64_t groups;                 // ceil(steps / 64)
-    uint64_t *group_sum;             // [groups]  scratch
-    uint64_t *group_excl;            // [groups]  out: exclusive offset (includes the base)
-    uint32_t *ticket;                // zero before the launch; reset by the last workgroup
-    uint64_t *out_count;             // device: *out_count = base + total
-    int accumulate;                  // 1: base = *out_count (index probes append)
+    uint32_t *group_sum;             // [groups]
+    unsigned long long *super_sum;   // [ceil(groups / 64) * kSuperStride], zeroed by K1
+    uint64_t *base_slot;             // scratch: first output slot of this query
+    const uint64_t *out_count;       // device result counter (read when accumulate)
+    int accumulate;                  // 1: IDs are appended after *out_count (index probes)
 };
 
-__global__ __launch_bounds__(kBlock) void scan_kernel(const ScanArgs a) {
-    __shared__ uint32_t s_last;
-    __shared__ uint64_t s_part[kBlock];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint64_t group = (uint64_t)blockIdx.x * kWaves + (tid >> 6);
-    if (group < a.groups) {
+__global__ __launch_bounds__(kBlock) void group_sum_kernel(const SumArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.base_slot = a.accumulate ? *a.out_count : 0;
+    for (uint64_t group = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); group < a.groups;
+         group += (uint64_t)gridDim.x * kWaves) {
         const uint64_t step = group * kGroupSteps + lane;
         const uint32_t c = step < a.steps ? (a.counts[step] & 0x0FFFFFFFu) : 0u;
         const uint32_t sum = wave_sum_u32(c);
-        if (lane == 0) a.group_sum[group] = sum;
+        if (lane == 0) {
+            a.group_sum[group] = sum;
+            if (sum) atomicAdd(&a.super_sum[(group / kSuperGroups) * kSuperStride], (unsigned long long)sum);
+        }
     }
-    // last workgroup to arrive scans the group sums (classic threadfence + ticket hand-off)
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const uint64_t per = (a.groups + kBlock - 1) / kBlock;
-    const uint64_t g0 = (uint64_t)tid * per, g1 = (g0 + per < a.groups) ? g0 + per : a.groups;
+}
+
+// COUNT / FLAGS modes: workgroup partial totals -> one number (no same-address atomics)
+__global__ __launch_bounds__(kBlock) void reduce_totals_kernel(const uint64_t *partials, uint32_t n, uint64_t *out_count) {
+    __shared__ uint64_t s_wave[kWaves];
     uint64_t local = 0;
-    for (uint64_t g = g0; g < g1; g++) local += __hip_atomic_load(&a.group_sum[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_part[tid] = local;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) local += partials[i];
+    local = wave_sum_u64(local);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = local;
     __syncthreads();
-    if (tid == 0) {
-        uint64_t run = a.accumulate ? *a.out_count : 0;
-        for (int i = 0; i < kBlock; i++) { const uint64_t t = s_part[i]; s_part[i] = run; run += t; }
-        *a.out_count = run;
-        *a.ticket = 0;                                           // ready for the next launch
-    }
-    __syncthreads();
-    uint64_t run = s_part[tid];
-    for (uint64_t g = g0; g < g1; g++) {
-        const uint64_t t = __hip_atomic_load(&a.group_sum[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.group_excl[g] = run;
-        run += t;
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int i = 0; i < kWaves; i++) t += s_wave[i];
+        *out_count = t;
     }
 }
 
@@ -421,7 +476,10 @@ __global__ __launch_bounds__(kBlock) void scan_kernel(const ScanArgs a) {
 struct ExpandArgs {
     const uint16_t *masks;
     const uint32_t *counts;
-    const uint64_t *group_excl;
+    const uint32_t *group_sum;
+    const unsigned long long *super_sum;
+    const uint64_t *base_slot;
+    uint64_t *out_count;             // written by the workgroup that owns the last group
     uint64_t steps;
     uint64_t groups;
     uint32_t *out_ids;
@@ -432,56 +490,114 @@ struct ExpandArgs {
     uint32_t gather;
 };
 
+constexpr int kStageIds = kStepRows;        // a step yields at most 1024 IDs
+
+// One step: K1 left 16 match bits per lane in its load layout (bit p of lane l <-> row
+// (p / RPL) * 64 * RPL + l * RPL + p % RPL).  First bring them into ROW order -- lane d gets the
+// bits of rows 16d .. 16d+15, which sit in 16/RPL source lanes -- then one wave scan gives every
+// lane its output rank; IDs are staged in LDS and written out with fully coalesced stores.
+template <int RL>                                               // log2(RPL): 2, 3 or 4
+__device__ __forceinline__ void expand_step(const ExpandArgs &a, uint64_t step, uint32_t m16, uint32_t count,
+                                            uint64_t out_off, uint64_t begin, uint32_t lane, uint32_t *stage) {
+    constexpr uint32_t RPL = 1u << RL, S = 16u / RPL;              // S source lanes per destination lane
+    uint32_t word;
+    if constexpr (S == 1) {
+        word = m16;
+    } else {
+        constexpr uint32_t LPC = 64u / S;                           // destination lanes per chunk
+        const uint32_t u = lane / LPC, first = S * (lane % LPC);
+        word = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < S; q++) {
+            const uint32_t src = (uint32_t)__shfl((int)m16, (int)(first + q), 64);
+            word |= ((src >> (RPL * u)) & ((1u << RPL) - 1u)) << (RPL * q);
+        }
+    }
+    const uint32_t cnt = __popc(word);
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    uint32_t pos = incl - cnt;
+    const uint32_t r0 = (uint32_t)(step * kStepRows) + lane * 16u;
+    while (word) {                                                  // set bits only, ascending rows
+        const uint32_t j = (uint32_t)__builtin_ctz(word);
+        word &= word - 1;
+        const uint32_t id = a.gather ? a.cand[begin + r0 + j] : r0 + j;
+        stage[pos++] = id + a.id_base;
+    }
+    // same wave wrote and reads: DS operations of one wave complete in order; the asm only
+    // stops the compiler from moving the reads above the writes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (uint32_t k = lane; k < count; k += 64) {
+        const uint64_t o = out_off + k;
+        if (o < a.out_cap) a.out_ids[o] = stage[k];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // reads done before the next step overwrites
+}
+
+__device__ __forceinline__ void expand_step_any(const ExpandArgs &a, uint64_t step, uint32_t m16, uint32_t rpl_log2,
+                                                uint32_t count, uint64_t out_off, uint64_t begin, uint32_t lane,
+                                                uint32_t *stage) {
+    switch (rpl_log2) {                                             // uniform
+    case 2: expand_step<2>(a, step, m16, count, out_off, begin, lane, stage); break;
+    case 3: expand_step<3>(a, step, m16, count, out_off, begin, lane, stage); break;
+    default: expand_step<4>(a, step, m16, count, out_off, begin, lane, stage); break;
+    }
+}
+
+// Workgroup per group of 64 steps.  Its first output slot is computed on the fly from the
+// supergroup sums (<= a few hundred values) and the <= 63 earlier group sums of its own
+// supergroup, so no serial scan kernel is needed.  The 4 waves then share the non-empty steps
+// round-robin and fetch the match bits of up to 4 steps at a time.
 __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint32_t s_part[kWaves];
+    __shared__ uint32_t s_stage[kWaves][kStageIds];
+    __shared__ uint16_t s_mask[kWaves][kGroupSteps / kWaves][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t begin = a.gather ? a.range[0] : 0;
-    for (uint64_t group = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); group < a.groups;
-         group += (uint64_t)gridDim.x * kWaves) {
+    const uint64_t base0 = *a.base_slot;
+    for (uint64_t group = blockIdx.x; group < a.groups; group += gridDim.x) {
+        // (1) counts of the 64 steps (every wave loads the same 256 bytes) + the sums in front
         const uint64_t my_step = group * kGroupSteps + lane;
         const uint32_t cw = my_step < a.steps ? a.counts[my_step] : 0u;
+        const uint64_t sg = group / kSuperGroups, g_in = group % kSuperGroups;
+        uint32_t part = 0;                                          // < 2^32: row IDs are u32
+        for (uint64_t j = tid; j < sg; j += kBlock) part += (uint32_t)a.super_sum[j * kSuperStride];
+        if (tid < g_in) part += a.group_sum[sg * kSuperGroups + tid];
         const uint32_t my_cnt = cw & 0x0FFFFFFFu;
-        uint64_t todo = __ballot(my_cnt != 0);
-        if (todo == 0) continue;                                   // nothing matched in these 64 K rows
-        // exclusive prefix of the 64 step counts (Hillis-Steele over the wave)
-        uint32_t incl = my_cnt;
+        const uint64_t nonempty = __ballot(my_cnt != 0);
+        const bool last_group = group + 1 == a.groups;
+        if (nonempty == 0 && !last_group) continue;                 // uniform for the workgroup
+        // (2) matches before this group
+        part = wave_sum_u32(part);
+        __syncthreads();                                            // previous iteration done with s_part
+        if (lane == 0) s_part[wave] = part;
+        __syncthreads();
+        uint64_t group_off = base0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += up;
+        for (int i = 0; i < kWaves; i++) group_off += s_part[i];
+        // (3) exclusive prefix of the step counts inside the group
+        const uint32_t incl = wave_incl_scan_u32(my_cnt);
+        const uint64_t my_off = group_off + (incl - my_cnt);
+        if (last_group && wave == 0 && lane == 63) *a.out_count = group_off + incl;
+        // (4) wave w owns steps w, w+4, ... of the group.  All their match-bit words are
+        // requested at once (one memory latency for up to 16 steps), parked in LDS, then expanded.
+        const uint16_t *gmask = a.masks + (group * kGroupSteps + wave) * 64 + lane;
+        uint32_t mreg[kGroupSteps / kWaves];
+#pragma unroll
+        for (int i = 0; i < kGroupSteps / kWaves; i++) {
+            mreg[i] = 0;
+            if ((nonempty >> (wave + kWaves * i)) & 1ull) mreg[i] = gmask[(size_t)i * kWaves * 64];   // uniform branch
         }
-        const uint64_t my_off = a.group_excl[group] + (incl - my_cnt);
-        while (todo) {                                             // uniform loop over non-empty steps
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint64_t step = group * kGroupSteps + (uint64_t)src;
-            const uint64_t step_off = __shfl(my_off, src, 64);
-            const uint32_t rpl_log2 = __shfl(cw, src, 64) >> 28;
-            const uint32_t rpl = 1u << rpl_log2, chunks = 16u >> rpl_log2;
-            const uint32_t m16 = a.masks[step * 64 + lane];
-            uint64_t base = step_off;
-            for (uint32_t u = 0; u < chunks; u++) {                 // rows ascend as (chunk, lane, j)
-                const uint32_t m = (m16 >> (u << rpl_log2)) & ((1u << rpl) - 1u);
-                const uint32_t cnt = __popc(m);                     // 0..rpl
-                // exclusive lane prefix from ballots of the count bits
-                uint32_t pre = 0, tot = 0;
-                for (uint32_t b = 0; b <= rpl_log2; b++) {
-                    const uint64_t bal = __ballot((cnt >> b) & 1u);
-                    pre += mbcnt(bal) << b;
-                    tot += (uint32_t)__popcll(bal) << b;
-                }
-                if (m) {
-                    uint64_t pos = base + pre;
-                    const uint64_t r0 = step * kStepRows + (uint64_t)u * 64 * rpl + lane * rpl;
-                    for (uint32_t j = 0; j < rpl; j++) {
-                        if (m & (1u << j)) {
-                            const uint32_t id = a.gather ? a.cand[begin + r0 + j] : (uint32_t)(r0 + j);
-                            if (pos < a.out_cap) a.out_ids[pos] = id + a.id_base;
-                            pos++;
-                        }
-                    }
-                }
-                base += tot;
-            }
+#pragma unroll
+        for (int i = 0; i < kGroupSteps / kWaves; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint64_t mine = nonempty >> wave;                           // bit 4i <-> my slot i
+        for (int i = 0; i < kGroupSteps / kWaves; i++, mine >>= kWaves) {
+            if (!(mine & 1ull)) continue;
+            const int sidx = (int)wave + kWaves * i;
+            const uint64_t step_off = __shfl(my_off, sidx, 64);
+            const uint32_t cwi = (uint32_t)__shfl((int)cw, sidx, 64);
+            expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
+                            cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
         }
     }
 }

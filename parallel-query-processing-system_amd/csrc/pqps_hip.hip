@@ -178,17 +178,20 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 constexpr int kMaxTimedLaunches = 4096;
+constexpr int kEvalBlocksPerCU = 16;     // grid cap of K1 (grid-stride beyond it)
 
 struct pqps_ctx {
     int device;
     int compute_units;
     hipStream_t stream;
-    // filter scratch, grown on demand: match bits, step counts, group sums / offsets, ticket
+    // filter scratch, grown on demand: match bits, step counts, group / supergroup sums
     uint64_t scratch_steps;     // capacity in steps of 1024 rows
     uint16_t *masks;
     uint32_t *counts;
-    uint64_t *group_sum, *group_excl;
-    uint32_t *ticket;
+    uint32_t *group_sum;        // [groups]
+    unsigned long long *super_sum;   // [supergroups]
+    uint64_t *base_slot;        // first output slot of the running query
+    uint64_t *partials;         // workgroup totals of K1 (COUNT / FLAGS modes)
     void *sort_tmp;
     size_t sort_tmp_bytes;
     // optional per-launch timing (bench.py roofline): K1 alone and K1..K3
@@ -201,23 +204,30 @@ namespace {
 
 hipStream_t pick_stream(pqps_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+void free_scratch(pqps_ctx *ctx) {
+    if (ctx->masks) (void)hipFree(ctx->masks);
+    if (ctx->counts) (void)hipFree(ctx->counts);
+    if (ctx->group_sum) (void)hipFree(ctx->group_sum);
+    if (ctx->super_sum) (void)hipFree(ctx->super_sum);
+    if (ctx->base_slot) (void)hipFree(ctx->base_slot);
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = nullptr; ctx->super_sum = nullptr;
+    ctx->base_slot = nullptr; ctx->partials = nullptr;
+    ctx->scratch_steps = 0;
+}
+
 int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     if (ctx->scratch_steps >= steps && ctx->masks) return PQPS_OK;
-    if (ctx->masks) {
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(ctx->masks); (void)hipFree(ctx->counts); (void)hipFree(ctx->group_sum);
-        (void)hipFree(ctx->group_excl); (void)hipFree(ctx->ticket);
-        ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = ctx->group_excl = nullptr; ctx->ticket = nullptr;
-        ctx->scratch_steps = 0;
-    }
+    if (ctx->masks) { HIP_TRY(hipDeviceSynchronize()); free_scratch(ctx); }
     const uint64_t cap = steps + steps / 4 + 64;
     const uint64_t groups = (cap + kGroupSteps - 1) / kGroupSteps;
+    const uint64_t supers = (groups + kSuperGroups - 1) / kSuperGroups;
     HIP_TRY(hipMalloc((void **)&ctx->masks, cap * 64 * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->group_sum, groups * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->group_excl, groups * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->ticket, 64));
-    HIP_TRY(hipMemset(ctx->ticket, 0, 64));
+    HIP_TRY(hipMalloc((void **)&ctx->group_sum, groups * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->super_sum, supers * kSuperStride * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&ctx->base_slot, 64));
+    HIP_TRY(hipMalloc((void **)&ctx->partials, (size_t)ctx->compute_units * kEvalBlocksPerCU * sizeof(uint64_t)));
     ctx->scratch_steps = cap;
     return PQPS_OK;
 }
@@ -305,7 +315,7 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
 
 uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps) {
     const uint64_t want = (steps + kWaves - 1) / kWaves;
-    const uint64_t cap = (uint64_t)ctx->compute_units * 16;
+    const uint64_t cap = (uint64_t)ctx->compute_units * kEvalBlocksPerCU;
     const uint64_t g = want < cap ? want : cap;
     return (uint32_t)(g ? g : 1);
 }
@@ -316,33 +326,42 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
+    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
     a.masks = ctx->masks;
     a.counts = ctx->counts;
-    a.out_count = (unsigned long long *)out_count;
+    a.partials = ctx->partials;
+    a.super_sum = ctx->super_sum;
+    a.n_super = (uint32_t)((groups + kSuperGroups - 1) / kSuperGroups);
+    const uint32_t grid = eval_grid(ctx, steps);
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
     if (timed) HIP_TRY(hipEventRecord(ctx->ev_start[ctx->timed], s));
-    if (steps) {
-        hipLaunchKernelGGL(k1, dim3(eval_grid(ctx, steps)), dim3(kBlock), 0, s, a);
-        HIP_TRY(hipGetLastError());
-    }
+    hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
+    HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ctx->ev_eval[ctx->timed], s));
-    if (mode == MODE_IDS) {
-        const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
-        ScanArgs sa;
-        sa.counts = ctx->counts; sa.steps = steps; sa.groups = groups;
-        sa.group_sum = ctx->group_sum; sa.group_excl = ctx->group_excl; sa.ticket = ctx->ticket;
-        sa.out_count = out_count; sa.accumulate = gather ? 1 : 0;
-        const uint32_t scan_blocks = (uint32_t)((groups + kWaves - 1) / kWaves);
-        hipLaunchKernelGGL(scan_kernel, dim3(scan_blocks ? scan_blocks : 1), dim3(kBlock), 0, s, sa);
+    if (mode != MODE_IDS) {
+        hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, out_count);
         HIP_TRY(hipGetLastError());
+    } else {
+        SumArgs sa;
+        sa.counts = ctx->counts; sa.steps = steps; sa.groups = groups;
+        sa.group_sum = ctx->group_sum; sa.super_sum = ctx->super_sum; sa.base_slot = ctx->base_slot;
+        sa.out_count = out_count; sa.accumulate = gather ? 1 : 0;
+        uint64_t sum_blocks = (groups + kWaves - 1) / kWaves;
+        if (sum_blocks > 2048) sum_blocks = 2048;
+        hipLaunchKernelGGL(group_sum_kernel, dim3((uint32_t)(sum_blocks ? sum_blocks : 1)), dim3(kBlock), 0, s, sa);
+        HIP_TRY(hipGetLastError());
+        ExpandArgs ea;
+        ea.masks = ctx->masks; ea.counts = ctx->counts; ea.group_sum = ctx->group_sum; ea.super_sum = ctx->super_sum;
+        ea.base_slot = ctx->base_slot; ea.out_count = out_count;
+        ea.steps = steps; ea.groups = groups; ea.out_ids = out_ids; ea.out_cap = out_cap;
+        ea.cand = a.cand; ea.range = a.range; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
         if (groups) {
-            ExpandArgs ea;
-            ea.masks = ctx->masks; ea.counts = ctx->counts; ea.group_excl = ctx->group_excl;
-            ea.steps = steps; ea.groups = groups; ea.out_ids = out_ids; ea.out_cap = out_cap;
-            ea.cand = a.cand; ea.range = a.range; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
-            const uint64_t want = (groups + kWaves - 1) / kWaves, cap = (uint64_t)ctx->compute_units * 8;
-            hipLaunchKernelGGL(expand_kernel, dim3((uint32_t)(want < cap ? want : cap)), dim3(kBlock), 0, s, ea);
+            const uint64_t cap = (uint64_t)ctx->compute_units * 32;
+            hipLaunchKernelGGL(expand_kernel, dim3((uint32_t)(groups < cap ? groups : cap)), dim3(kBlock), 0, s, ea);
             HIP_TRY(hipGetLastError());
+        } else {
+            // no rows at all: the count is the base (0, or unchanged when appending)
+            if (!gather) HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
         }
     }
     if (timed) { HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
@@ -378,7 +397,8 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->scratch_steps = 0;
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = ctx->group_excl = nullptr; ctx->ticket = nullptr;
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = nullptr; ctx->super_sum = nullptr;
+    ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
@@ -394,10 +414,7 @@ void pqps_ctx_destroy(pqps_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->masks) {
-        (void)hipFree(ctx->masks); (void)hipFree(ctx->counts); (void)hipFree(ctx->group_sum);
-        (void)hipFree(ctx->group_excl); (void)hipFree(ctx->ticket);
-    }
+    free_scratch(ctx);
     if (ctx->sort_tmp) (void)hipFree(ctx->sort_tmp);
     if (ctx->ev_start) {
         for (int i = 0; i < kMaxTimedLaunches; i++) {
@@ -524,7 +541,6 @@ int pqps_filter_count(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
     return run_filter(ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred), a, n_rows, MODE_COUNT, false,
                       0, nullptr, 0, out_count, s);
 }
@@ -540,7 +556,6 @@ int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
     a.out_flags = out_flags;
-    HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
     return run_filter(ctx, eval_generic_kernel<MODE_FLAGS, false>, a, n_rows, MODE_FLAGS, false,
                       0, nullptr, 0, out_count, s);
 }
