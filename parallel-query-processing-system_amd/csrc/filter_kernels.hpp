@@ -154,6 +154,67 @@ __device__ __forceinline__ uint32_t combine_leaves(const EvalArgs &a, const uint
     return m;
 }
 
+// ---- row-mask evaluation (<= 6 leaves) -----------------------------------------------------
+// A leaf is evaluated for the R rows of a lane into an R-bit mask (bit r = row r) with the
+// cheapest compare that decides it: equality (span == 0), one-sided (lo == 0) or the window.
+// The boolean tree is then applied ONCE per step on the leaf masks -- a handful of AND / OR /
+// NOT on 16-bit masks -- instead of a truth-table lookup per row.
+template <typename T, int R>
+__device__ __forceinline__ uint32_t leaf_mask(const T (&v)[R], T lo, T span) {
+    uint32_t m = 0;
+    if (span == 0) {                                            // uniform: x == lo
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) m = (m << 1) | (v[r] == lo ? 1u : 0u);
+    } else if (lo == 0) {                                       // uniform: x <= span
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) m = (m << 1) | (v[r] <= span ? 1u : 0u);
+    } else {
+#pragma unroll
+        for (int r = R - 1; r >= 0; r--) m = (m << 1) | ((T)(v[r] - lo) <= span ? 1u : 0u);
+    }
+    return m;
+}
+
+struct LeafMasks { uint32_t m[PQPS_TT_LEAVES]; };
+
+template <typename T, int R>
+__device__ __forceinline__ void apply_leaves_masks(const EvalArgs &a, uint32_t kb, uint32_t ke,
+                                                   const T (&v)[R], LeafMasks &lm) {
+    for (uint32_t k = kb; k < ke; k++) {                        // uniform; operands come in SGPRs
+        uint32_t m = leaf_mask<T, R>(v, (T)a.lo[k], (T)a.span[k]);
+        if ((a.negmask >> k) & 1u) m = ~m;
+        switch (k) {                                            // uniform: keeps lm in registers
+        case 0: lm.m[0] = m; break;
+        case 1: lm.m[1] = m; break;
+        case 2: lm.m[2] = m; break;
+        case 3: lm.m[3] = m; break;
+        case 4: lm.m[4] = m; break;
+        default: lm.m[5] = m; break;
+        }
+    }
+}
+
+// OR over the true rows of the truth table of AND over leaves (leaf or its complement).
+// When more than half of the table is true the complement is expanded instead.
+__device__ __forceinline__ uint32_t combine_masks(const EvalArgs &a, const LeafMasks &lm, uint32_t full) {
+    const uint32_t n = a.n_leaves;
+    const uint64_t all = n >= 6 ? ~0ull : ((1ull << (1u << n)) - 1ull);
+    uint64_t tt = a.truth & all;
+    const bool invert = (uint32_t)__popcll(tt) > (1u << n) / 2;
+    if (invert) tt = ~tt & all;
+    uint32_t res = 0;
+    while (tt) {                                                // uniform loop over true entries
+        const uint32_t e = (uint32_t)__builtin_ctzll(tt);
+        tt &= tt - 1;
+        uint32_t term = full;
+#pragma unroll
+        for (uint32_t k = 0; k < PQPS_TT_LEAVES; k++)
+            if (k < n) term &= ((e >> k) & 1u) ? lm.m[k] : ~lm.m[k];
+        res |= term;
+    }
+    return (invert ? ~res : res) & full;
+}
+
 // ---- per-step output ---------------------------------------------------------------
 // Bit p of a lane's 16 match bits <-> row  step_row0 + (p / RPL) * 64 * RPL + lane * RPL + p % RPL.
 template <int MODE>
@@ -161,7 +222,17 @@ __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint
                                           uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
     const uint32_t cnt = wave_sum_u32(__popc(mbits));
     if (MODE == MODE_IDS) {
-        if (cnt) a.masks[step * 64 + lane] = (uint16_t)mbits;    // 128 B per step, only if needed
+        if (cnt) {                                               // 128 B per step, only if needed
+            // gather the 16-bit words of 8 neighbouring lanes into one lane -> 8 lanes store 16 B each
+            const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // lane pairs (even lanes valid)
+            const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lane+2's pair
+            const uint32_t q0 = w2, q1 = w2b;                                              // lanes 0 mod 4: words 0..3
+            const uint32_t q2 = dpp_or_zero<0x104>(q0), q3 = dpp_or_zero<0x104>(q1);       // row_shl:4 -> lane+4's words
+            if ((lane & 7u) == 0) {
+                uint4 v; v.x = q0; v.y = q1; v.z = q2; v.w = q3;
+                *(uint4 *)(a.masks + step * 64 + lane) = v;
+            }
+        }
         if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
     } else {
         wave_total += cnt;
@@ -368,6 +439,20 @@ __device__ __forceinline__ void unpack64(const RawCol<W, RPL, U> &raw, uint64_t 
 }
 
 template <int W, int RPL, int U>
+__device__ __forceinline__ void eval_col_masks(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, LeafMasks &lm) {
+    const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
+    if constexpr (W == 8) {
+        uint64_t v[16];
+        unpack64(raw, v, std::make_integer_sequence<int, 16>{});
+        apply_leaves_masks<uint64_t, 16>(a, kb, ke, v, lm);
+    } else {
+        uint32_t v[16];
+        unpack32(raw, v, std::make_integer_sequence<int, 16>{});
+        apply_leaves_masks<uint32_t, 16>(a, kb, ke, v, lm);
+    }
+}
+
+template <int W, int RPL, int U>
 __device__ __forceinline__ void eval_col(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&idx)[16]) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
@@ -383,6 +468,37 @@ __device__ __forceinline__ void eval_col(const EvalArgs &a, int slot, const RawC
 
 constexpr int log2i(int x) { return x <= 1 ? 0 : 1 + log2i(x / 2); }
 
+// All raw registers of one step for the (W0, W1, W2) shape.
+template <int W0, int W1, int W2, int RPL, int U>
+struct RawStep {
+    RawCol<W0, RPL, U> r0;
+    RawCol<(W1 ? W1 : 1), RPL, U> r1;
+    RawCol<(W2 ? W2 : 1), RPL, U> r2;
+    __device__ __forceinline__ void load(const EvalArgs &a, uint64_t lane_row0) {
+        r0.load(a.col[0], lane_row0);
+        if constexpr (W1 != 0) r1.load(a.col[1], lane_row0);
+        if constexpr (W2 != 0) r2.load(a.col[2], lane_row0);
+    }
+    __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {
+        if (a.n_leaves <= PQPS_TT_LEAVES) {                     // uniform: row-mask path
+            LeafMasks lm;
+#pragma unroll
+            for (int k = 0; k < PQPS_TT_LEAVES; k++) lm.m[k] = 0;
+            eval_col_masks<W0, RPL, U>(a, 0, r0, lm);
+            if constexpr (W1 != 0) eval_col_masks<W1, RPL, U>(a, 1, r1, lm);
+            if constexpr (W2 != 0) eval_col_masks<W2, RPL, U>(a, 2, r2, lm);
+            return combine_masks(a, lm, 0xFFFFu);
+        }
+        uint32_t idx[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) idx[r] = 0;
+        eval_col<W0, RPL, U>(a, 0, r0, idx);
+        if constexpr (W1 != 0) eval_col<W1, RPL, U>(a, 1, r1, idx);
+        if constexpr (W2 != 0) eval_col<W2, RPL, U>(a, 2, r2, idx);
+        return combine_leaves<16>(a, idx);
+    }
+};
+
 // W0 >= W1 >= W2 are the byte widths of the predicate columns (0 = slot unused).
 template <int MODE, int W0, int W1, int W2>
 __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
@@ -390,31 +506,38 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;                                 // chunks per step
+    // narrow shapes keep few bytes in flight per wave: double-buffer their loads (the
+    // next step is requested before the current one is evaluated)
+    constexpr bool PREFETCH = false;       // measured: the extra registers cost more occupancy than the overlap wins
     clear_super_sums<MODE>(a);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
     const uint64_t n_rows = a.n_rows;
     const uint64_t full_steps = n_rows / kStepRows;
+    const uint64_t lane_off = lane * RPL;
     uint64_t wave_total = 0;
 
-    for (uint64_t step = wave; step < full_steps; step += n_waves) {
-        const uint64_t lane_row0 = step * kStepRows + lane * RPL;
-        RawCol<W0, RPL, U> r0;
-        r0.load(a.col[0], lane_row0);
-        RawCol<(W1 ? W1 : 1), RPL, U> r1;
-        if constexpr (W1 != 0) r1.load(a.col[1], lane_row0);
-        RawCol<(W2 ? W2 : 1), RPL, U> r2;
-        if constexpr (W2 != 0) r2.load(a.col[2], lane_row0);
-
-        uint32_t idx[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) idx[r] = 0;
-        eval_col<W0, RPL, U>(a, 0, r0, idx);
-        if constexpr (W1 != 0) eval_col<W1, RPL, U>(a, 1, r1, idx);
-        if constexpr (W2 != 0) eval_col<W2, RPL, U>(a, 2, r2, idx);
-        const uint32_t mbits = combine_leaves<16>(a, idx);
-        emit_step<MODE>(a, step, mbits, log2i(RPL), n_rows, lane, wave_total);
+    if constexpr (PREFETCH) {
+        RawStep<W0, W1, W2, RPL, U> A, B;
+        uint64_t step = wave;
+        if (step < full_steps) A.load(a, step * kStepRows + lane_off);
+        while (step < full_steps) {
+            const uint64_t s1 = step + n_waves;
+            if (s1 < full_steps) B.load(a, s1 * kStepRows + lane_off);
+            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
+            if (s1 >= full_steps) break;
+            const uint64_t s2 = s1 + n_waves;
+            if (s2 < full_steps) A.load(a, s2 * kStepRows + lane_off);
+            emit_step<MODE>(a, s1, B.eval(a), log2i(RPL), n_rows, lane, wave_total);
+            step = s2;
+        }
+    } else {
+        for (uint64_t step = wave; step < full_steps; step += n_waves) {
+            RawStep<W0, W1, W2, RPL, U> A;
+            A.load(a, step * kStepRows + lane_off);
+            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
+        }
     }
     // the partial last step (if any) goes through the guarded evaluator, RPL = 4 layout
     if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
