@@ -275,6 +275,7 @@ def main():
     alg_bytes = count * bytes_per_row + 4 * local_matches          # n * sum w(c) + 4 * matches
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
+    traffic, traffic_src = pmc_traffic(args.query, args.rows) if world == 1 else (None, None)
     result = {
         "metric": "rows/sec SELECT-filter on commands_* schema",
         "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,7 +288,7 @@ def main():
                    "parallelism": f"row-range shards x{world}" + (", RCCL count+ID all-gather merge on every rank" if world > 1 else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "eval_spec_kernel / eval_generic_kernel (K1: the only kernel that reads the table)",
                      "avg_kernel_ms": avg_kernel_ms, "avg_pipeline_ms": pipe_ms / max(launches, 1),
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
@@ -302,6 +303,24 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def pmc_traffic(query, rows):
+    """HBM bytes per launch of the evaluate kernel from the committed rocprofv3 PMC summary of
+    this same workload (profiles/rNN_<query>_<rows>_pmc.json, made by scripts/profile_pmc.sh +
+    scripts/summarize_profiles.py: separate --pmc passes, FETCH_SIZE x 1024 x 2 for the gfx950
+    half-count of wide coalesced reads, WRITE_SIZE x 1024).  None when no profile matches."""
+    tag = {100_000_000: "100m", 1_000_000_000: "1b"}.get(rows)
+    if tag is None:
+        return None, None
+    files = sorted((ROOT / "profiles").glob(f"r*_{query.lower()}_{tag}_pmc.json"))
+    if not files:
+        return None, None
+    d = json.loads(files[-1].read_text())
+    k1 = [v for k, v in d.items() if k.startswith("K1_")]
+    if not k1 or "hbm_read_bytes_per_launch" not in k1[0]:
+        return None, None
+    return k1[0]["hbm_read_bytes_per_launch"] + k1[0].get("hbm_write_bytes_per_launch", 0.0), files[-1].name
 
 
 def _leaves(chain):
