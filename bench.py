@@ -84,7 +84,7 @@ def cpu_baseline(pq, chain, sql, seed, log):
         port["omp"] = omp
         return port
     # the real reference over AoS records built from the same synthetic columns
-    n_aos = 8_000_000
+    n_aos = 12_000_000
     rec_dt = np.dtype({"names": ["command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
                                  "sudo_used", "working_directory", "user_id", "user_name", "host_name", "risk_level"],
                        "formats": ["<u8", "S512", "S100", "S20", "<i4", "S30", "u1", "S200", "<i4", "S50", "S100", "<i4"],

@@ -19,4 +19,10 @@ def _oracle_built():
     src = qpelib.ORACLE_DIR / "qpe_oracle.c"
     if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
         qpelib.build_oracle()
+    # the product library (hipcc cross-compiles gfx950 without a GPU); `make` is a no-op when fresh
+    lib = qpelib.pq.LIB_PATH
+    srcs = [p for pat in ("csrc/*", "engine/hip/*.c", "host/*.c") for p in qpelib.PKG.glob(pat)]
+    srcs += list((qpelib.ROOT / "include").glob("*.h"))
+    if not lib.exists() or lib.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
+        qpelib.pq.build_library()
     yield
