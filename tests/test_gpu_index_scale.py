@@ -1,0 +1,148 @@
+"""BASELINE configs[2]: index range-probe SELECT at synthetic scale, through the C-ABI shim.
+
+pqps_index_build (perm sorted key asc / row desc = leaf order of the reference's B+ tree,
+bplus.c:282-358,471-517) + pqps_index_probe (inclusive window) + pqps_filter_gather
+(order-preserving re-filter with the complete WHERE, appended probe after probe) against a
+numpy restatement of executeQuerySelectSerial's index path (serial:358-474) over the host
+twin of the same seeded table.  5 M rows bit-exact, 100 M rows by properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import qpelib as q
+
+pq = q.pq
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pq.Context(0)
+    yield c
+    c.close()
+
+
+class DeviceIndex:
+    def __init__(self, ctx, table, name, signed):
+        self.ctx, self.table, self.signed = ctx, table, signed
+        self.width = table.width[name]
+        n = max(table.n, 1)
+        self.perm = ctx.malloc(4 * n)
+        self.keys = ctx.malloc(self.width * n)
+        col = pq.column_array([(table.ptr[name], self.width)])
+        pq.check(pq.lib().pqps_index_build(ctx.h, col, table.n, 1 if signed else 0, self.perm, self.keys, None), "index build")
+
+    def free(self):
+        self.ctx.free(self.perm)
+        self.ctx.free(self.keys)
+
+
+def index_select(ctx, table, probes, chain, out_ids, cap, scratch):
+    """probes: [(DeviceIndex, key_lo, key_hi)] in the order QPESeq would probe them."""
+    pred, cols, nc, _ = table.bind(chain)
+    count_dev, range_dev = scratch, scratch + 16
+    ctx.memset(count_dev, 0, 8)
+    L = pq.lib()
+    for ix, lo, hi in probes:
+        pq.check(L.pqps_index_probe(ctx.h, ix.keys, ix.width, 1 if ix.signed else 0, table.n,
+                                    lo & 0xFFFFFFFFFFFFFFFF, hi & 0xFFFFFFFFFFFFFFFF, range_dev, None), "probe")
+        pq.check(L.pqps_filter_gather(ctx.h, cols, nc, ix.perm, range_dev, table.n, 0, C.byref(pred),
+                                      out_ids, cap, count_dev, None), "gather")
+    ctx.sync()
+    k = C.c_uint64()
+    ctx.download(C.byref(k), count_dev, 8)
+    ids = np.zeros(max(min(k.value, cap), 1), dtype=np.uint32)
+    if k.value:
+        ctx.download(ids.ctypes.data, out_ids, 4 * min(k.value, cap))
+    return ids[:min(k.value, cap)], k.value
+
+
+def host_index_order(keys):
+    """(key asc, row desc): stable sort of the rows fed in descending order."""
+    n = len(keys)
+    rev = np.arange(n - 1, -1, -1, dtype=np.int64)
+    return rev[np.argsort(keys[rev], kind="stable")]
+
+
+def host_index_select(host, perms, probes, chain):
+    full = np.zeros(host.n, dtype=bool)
+    full[host.oracle_scan(chain)] = True
+    out = []
+    for name, lo, hi in probes:
+        perm = perms[name]
+        k = host.arr[name][perm]
+        b, e = np.searchsorted(k, lo, "left"), np.searchsorted(k, hi, "right")
+        cand = perm[b:max(b, e)]
+        out.append(cand[full[cand]])
+    return np.concatenate(out).astype(np.uint32) if out else np.zeros(0, np.uint32)
+
+
+I32_MIN, I32_MAX = -2**31, 2**31 - 1
+
+
+def test_index_mode_matches_serial_semantics_5m(ctx):
+    n = 5_000_000
+    dev = pq.SyntheticTable(ctx, n, seed=21)
+    host = q.HostSynth(n, seed=21)
+    ix = {"risk_level": DeviceIndex(ctx, dev, "risk_level", True), "user_id": DeviceIndex(ctx, dev, "user_id", True),
+          "command_id": DeviceIndex(ctx, dev, "command_id", False), "exit_code": DeviceIndex(ctx, dev, "exit_code", True)}
+    perms = {name: host_index_order(host.arr[name]) for name in ix}
+    for name, d in ix.items():                                   # leaf order itself
+        p = np.zeros(n, dtype=np.uint32)
+        ctx.download(p.ctypes.data, d.perm, 4 * n)
+        assert np.array_equal(p, perms[name].astype(np.uint32)), name
+    out = ctx.malloc(4 * 3 * n)
+    scratch = ctx.malloc(256)
+    cases = [
+        # (probes in chain order, WHERE)
+        ([("risk_level", 4, I32_MAX)], [("risk_level", ">", "3")]),                                        # Sample 3
+        ([("risk_level", 5, 5)], [("risk_level", "=", "5")]),                                               # Sample 4
+        ([("risk_level", 3, I32_MAX)], [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")]),      # Sample 2
+        ([("user_id", 1001, 1001)], [("user_id", "=", "1001"), "OR", [("user_name", "=", "student1002"), "AND", ("shell_type", "=", "zsh")]]),
+        ([("command_id", n - 1000, 2**64 - 1)], [("command_id", ">=", str(n - 1000))]),
+        ([("command_id", 0, 9)], [("command_id", "<", "10")]),
+        ([("risk_level", I32_MIN, I32_MAX)], [("risk_level", "!=", "1")]),                                 # != probes everything
+        ([("risk_level", 4, I32_MAX), ("exit_code", 130, 130)], [("risk_level", ">=", "4"), "AND", ("exit_code", "=", "130")]),   # duplicates
+        ([("risk_level", 5, 5)], [("risk_level", "=", "5"), "OR", ("user_name", "=", "student1030")]),     # OR-loss
+        ([("user_id", 2990, I32_MAX), ("user_id", I32_MIN, 1003)], [("user_id", ">=", "2990"), "OR", ("user_id", "<=", "1003")]),
+        ([("risk_level", 9, I32_MAX)], [("risk_level", ">", "8")]),                                         # empty range
+    ]
+    for probes, chain in cases:
+        got, k = index_select(ctx, dev, [(ix[nm], lo, hi) for nm, lo, hi in probes], chain, out, 3 * n, scratch)
+        want = host_index_select(host, perms, probes, chain)
+        assert k == len(want) and np.array_equal(got, want), chain
+    for d in ix.values():
+        d.free()
+    ctx.free(out)
+    ctx.free(scratch)
+    dev.free()
+
+
+def test_index_probe_100m_properties(ctx):
+    n = 100_000_000
+    dev = pq.SyntheticTable(ctx, n, seed=0x5EED, columns=["risk_level", "exit_code", "sudo_used"])
+    ix = DeviceIndex(ctx, dev, "risk_level", True)
+    out = ctx.malloc(4 * (n // 8))
+    scratch = ctx.malloc(256)
+    chain = [("risk_level", ">", "3"), "AND", ("exit_code", "=", "0")]
+    got, k = index_select(ctx, dev, [(ix, 4, I32_MAX)], chain, out, n // 8, scratch)
+    # same set as the scan-mode answer ...
+    pred, cols, nc, _ = dev.bind(chain)
+    cnt = ctx.malloc(64)
+    pq.check(pq.lib().pqps_filter_count(ctx.h, cols, nc, n, C.byref(pred), cnt, None))
+    ctx.sync()
+    c = C.c_uint64()
+    ctx.download(C.byref(c), cnt, 8)
+    assert k == c.value == len(got) and len(np.unique(got)) == k
+    # ... in index order: keys ascending, rows descending inside a key
+    risk = np.zeros(n, dtype=np.int32)
+    ctx.download(risk.ctypes.data, dev.ptr["risk_level"], 4 * n)
+    kk = risk[got]
+    assert np.all(kk[1:] >= kk[:-1]) and set(np.unique(kk)) == {4, 5}
+    same = kk[1:] == kk[:-1]
+    assert np.all(got[1:][same] < got[:-1][same])
+    for p in (out, scratch, cnt):
+        ctx.free(p)
+    ix.free()
+    dev.free()
