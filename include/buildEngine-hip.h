@@ -30,8 +30,9 @@ enum {
 /* Sorted (strcmp byte order) distinct values of one string column. */
 struct hipDictionary {
     int count;
-    const char **values;     /* count pointers into `storage`, ascending */
+    const char **values;     /* `count` strings, ascending; into `storage` or (after INSERT) strdup'd */
     char *storage;
+    size_t storage_bytes;
 };
 
 /* One B+-tree replacement: device permutation + sorted keys. */
@@ -54,6 +55,7 @@ struct hipTable {
     uint64_t capacity_ids;
     uint64_t *count_dev;                         /* 4 x u64: count, range[2], spare        */
     record *row_block;                           /* contiguous host rows (all_records[i] point in) */
+    size_t row_capacity;                         /* rows row_block / all_records have room for      */
 };
 
 /* CSV -> contiguous block of records + pointer array (reference signature of
@@ -73,6 +75,8 @@ bool buildDeviceTableHIP(struct engineS *engine);
 /* Re-creates columns, dictionaries and indexes from engine->all_records
  * (after INSERT / DELETE changed the host rows). */
 void rebuildDeviceTableHIP(struct engineS *engine);
+/* INSERT: appends engine->all_records[num_records-1] to the device table in place. */
+void appendRowDeviceTableHIP(struct engineS *engine);
 void destroyDeviceTableHIP(struct engineS *engine);
 
 /* Lower-level pieces (also used for ad-hoc tables over caller-supplied rows,

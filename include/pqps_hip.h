@@ -115,6 +115,11 @@ int  pqps_memset(pqps_ctx *ctx, void *dptr, int value, size_t bytes, void *strea
 int  pqps_upload(pqps_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int  pqps_download(pqps_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 
+/* codes[i] += 1 for every i < n_rows with codes[i] >= threshold (`width` 1, 2 or 4 bytes).
+ * Keeps the dictionary codes of a string column order-preserving when INSERT adds a value
+ * at rank `threshold`. */
+int pqps_bump_codes(pqps_ctx *ctx, void *codes, uint32_t width, uint64_t n_rows, uint32_t threshold, void *stream);
+
 /* Scan mode.  Evaluates `pred` on rows [0, n_rows) of `cols` and writes the
  * matching row IDs (row + id_base, u32) in ASCENDING row order to out_ids and
  * their number to *out_count (device u64).  Asynchronous on `stream`.

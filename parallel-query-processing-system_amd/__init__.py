@@ -233,6 +233,7 @@ def lib():
     L.pqps_synth_generate_host.argtypes = [u64, u64, u64, vp, vp, C.POINTER(SynthCols)]
     L.pqps_synth_generate_host.restype = None
     L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
+    L.pqps_bump_codes.argtypes = [vp, vp, u32, u64, u32, vp]
     L.pqps_merge_segments.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
     L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.hipColumnId.argtypes = [C.c_char_p]

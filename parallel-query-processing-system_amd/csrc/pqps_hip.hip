@@ -140,6 +140,15 @@ __global__ __launch_bounds__(256) void merge_segments_kernel(const uint32_t *seg
     }
 }
 
+// ---- INSERT support: shift dictionary codes at or above a new value's rank -----------------
+template <typename T>
+__global__ void bump_codes_kernel(T *codes, uint64_t n, uint32_t threshold) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const T c = codes[i];
+        if ((uint32_t)c >= threshold) codes[i] = (T)(c + 1);
+    }
+}
+
 // ---- streaming read probe ----------------------------------------------------
 __global__ __launch_bounds__(256) void read_probe_kernel(const uint4 *p, uint64_t n16, uint64_t *out) {
     uint64_t acc = 0;
@@ -711,6 +720,20 @@ void pqps_synth_generate_host(uint64_t seed, uint64_t row0, uint64_t n,
                               const uint32_t *user_cdf, const uint8_t *user_shell,
                               const pqps_synth_cols *out) {
     for (uint64_t i = 0; i < n; i++) synth_store(*out, i, synth_row(seed, row0 + i, user_cdf, user_shell));
+}
+
+int pqps_bump_codes(pqps_ctx *ctx, void *codes, uint32_t width, uint64_t n_rows, uint32_t threshold, void *stream) {
+    if (!ctx || (!codes && n_rows)) return fail(PQPS_EINVAL, "NULL argument");
+    if (n_rows == 0) return PQPS_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t want = (n_rows + 255) / 256;
+    const uint32_t blocks = (uint32_t)(want < 8192 ? want : 8192);
+    if (width == 1) hipLaunchKernelGGL((bump_codes_kernel<uint8_t>), dim3(blocks), dim3(256), 0, s, (uint8_t *)codes, n_rows, threshold);
+    else if (width == 2) hipLaunchKernelGGL((bump_codes_kernel<uint16_t>), dim3(blocks), dim3(256), 0, s, (uint16_t *)codes, n_rows, threshold);
+    else if (width == 4) hipLaunchKernelGGL((bump_codes_kernel<uint32_t>), dim3(blocks), dim3(256), 0, s, (uint32_t *)codes, n_rows, threshold);
+    else return fail(PQPS_EINVAL, "code width %u not in {1,2,4}", width);
+    HIP_TRY(hipGetLastError());
+    return PQPS_OK;
 }
 
 int pqps_merge_segments(pqps_ctx *ctx, const uint32_t *segments, const uint64_t *counts, uint32_t world,

@@ -15,10 +15,12 @@
 #include "buildEngine-hip.h"
 #include "hipPredicate.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <unistd.h>
 
 /* ---- CSV ------------------------------------------------------------------ */
 
@@ -81,9 +83,56 @@ record *getRecordFromLineHIP(char *line) {
     return r;
 }
 
+/* ---- small fork-join helper (pthreads) -------------------------------------------- */
+struct par_task { void (*fn)(void *, size_t, size_t); void *arg; size_t begin, end; };
+
+static void *par_entry(void *p) {
+    struct par_task *t = p;
+    t->fn(t->arg, t->begin, t->end);
+    return NULL;
+}
+
+static int host_threads(void) {
+    const char *env = getenv("PQPS_HOST_THREADS");
+    long n = env ? atol(env) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (n > 32) n = 32;
+    return (int)n;
+}
+
+/* fn(arg, begin, end) over [0, n) split into contiguous ranges, one per thread */
+static void parallel_for(size_t n, void (*fn)(void *, size_t, size_t), void *arg) {
+    int nt = host_threads();
+    if ((size_t)nt > n / 1024 + 1) nt = (int)(n / 1024 + 1);
+    if (nt <= 1) { fn(arg, 0, n); return; }
+    pthread_t tid[32];
+    struct par_task task[32];
+    for (int i = 0; i < nt; i++) {
+        task[i].fn = fn; task[i].arg = arg;
+        task[i].begin = n * (size_t)i / (size_t)nt;
+        task[i].end = n * (size_t)(i + 1) / (size_t)nt;
+        if (pthread_create(&tid[i], NULL, par_entry, &task[i]) != 0) { fn(arg, task[i].begin, task[i].end); tid[i] = 0; }
+    }
+    for (int i = 0; i < nt; i++) if (tid[i]) pthread_join(tid[i], NULL);
+}
+
 /* getAllRecordsFromFile, buildEngine-serial.c:70-108, with the block
  * allocation of the OMP variant (buildEngine-omp.c:84): rows are the fgets()
- * chunks of the file (<= 1023 bytes each) after the first one. */
+ * chunks of the file (<= 1023 bytes each, a chunk also ends after '\n') after
+ * the first one.  The chunk boundaries are found in one sequential pass, the
+ * rows are parsed in parallel (reference analogue: buildEngine-omp.c:157). */
+struct parse_job { const char *text; const size_t *start; const uint32_t *len; record *block; };
+
+static void parse_range(void *arg, size_t begin, size_t end) {
+    struct parse_job *j = arg;
+    char line[1024];
+    for (size_t i = begin; i < end; i++) {
+        memcpy(line, j->text + j->start[i], j->len[i]);
+        line[j->len[i]] = '\0';                          /* fgets() semantics: C string, at most 1023 bytes */
+        fillRecordFromLineHIP(&j->block[i], line);
+    }
+}
+
 record **getAllRecordsFromFileHIP(const char *filepath, int *num_records, void **record_block_out) {
     *num_records = 0;
     if (record_block_out) *record_block_out = NULL;
@@ -92,25 +141,41 @@ record **getAllRecordsFromFileHIP(const char *filepath, int *num_records, void *
         fprintf(stderr, "Error opening file: %s\n", filepath);
         return NULL;
     }
-    size_t cap = 4096, n = 0;
-    record *block = malloc(cap * sizeof *block);
-    char line[1024];
-    int first = 1;
-    while (block && fgets(line, sizeof line, f)) {
-        if (first) { first = 0; continue; }
-        if (n == cap) {
-            cap *= 2;
-            record *grown = realloc(block, cap * sizeof *block);
-            if (!grown) { free(block); block = NULL; break; }
-            block = grown;
-        }
-        fillRecordFromLineHIP(&block[n++], line);
-    }
+    fseek(f, 0, SEEK_END);
+    const long fsize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *text = malloc((size_t)(fsize > 0 ? fsize : 0) + 1);
+    size_t got = text ? fread(text, 1, (size_t)(fsize > 0 ? fsize : 0), f) : 0;
     fclose(f);
-    if (!block) { fprintf(stderr, "Memory allocation failed\n"); return NULL; }
+    if (!text) { fprintf(stderr, "Memory allocation failed\n"); return NULL; }
+    text[got] = '\0';
+
+    /* pass 1: chunk table (what successive fgets(line, 1024) calls would return) */
+    size_t cap = got / 64 + 16, chunks = 0;
+    size_t *start = malloc(cap * sizeof *start);
+    uint32_t *len = malloc(cap * sizeof *len);
+    for (size_t pos = 0; start && len && pos < got;) {
+        size_t l = 0;
+        while (l < 1023 && pos + l < got) { const char ch = text[pos + l]; l++; if (ch == '\n') break; }
+        if (chunks == cap) {
+            cap *= 2;
+            start = realloc(start, cap * sizeof *start);
+            len = realloc(len, cap * sizeof *len);
+            if (!start || !len) break;
+        }
+        start[chunks] = pos; len[chunks] = (uint32_t)l; chunks++;
+        pos += l;
+    }
+    if (!start || !len) { fprintf(stderr, "Memory allocation failed\n"); free(text); free(start); free(len); return NULL; }
+    const size_t n = chunks > 0 ? chunks - 1 : 0;        /* first chunk = header, dropped unconditionally */
+
+    record *block = malloc((n ? n : 1) * sizeof *block);
     record **rows = malloc((n ? n : 1) * sizeof *rows);
-    if (!rows) { free(block); fprintf(stderr, "Memory allocation failed\n"); return NULL; }
+    if (!block || !rows) { fprintf(stderr, "Memory allocation failed\n"); free(text); free(start); free(len); free(block); free(rows); return NULL; }
+    struct parse_job job = { text, start + 1, len + 1, block };
+    parallel_for(n, parse_range, &job);
     for (size_t i = 0; i < n; i++) rows[i] = &block[i];
+    free(text); free(start); free(len);
     *num_records = (int)n;
     if (record_block_out) *record_block_out = block; else if (n == 0) free(block);
     return rows;
@@ -139,45 +204,69 @@ static const int k_kind[HIPCOL_COUNT] = {
     HIPKIND_BOOL, HIPKIND_DICT, HIPKIND_I32, HIPKIND_DICT, HIPKIND_DICT, HIPKIND_I32
 };
 
-static int cmp_cstr_ptr(const void *a, const void *b) {
-    return strcmp(*(const char *const *)a, *(const char *const *)b);
+static int cmp_cstr_ptr_ptr(const void *a, const void *b) {
+    return strcmp(**(const char *const *const *)a, **(const char *const *const *)b);
 }
 
-/* Sorted distinct values of one string column.  The "value" of a row is the
- * C string that starts at the field -- exactly what strcmp() in the
- * reference's CMP_STR sees, including the run-on into the next field when
- * strncpy left no terminator (buildEngine-serial.c:171). */
+static uint64_t hash_cstr(const char *s) {                      /* FNV-1a */
+    uint64_t h = 1469598103934665603ull;
+    for (; *s; s++) { h ^= (unsigned char)*s; h *= 1099511628211ull; }
+    return h;
+}
+
+/* Sorted distinct values of one string column + the code (rank) of every row.
+ * The "value" of a row is the C string that starts at the field -- exactly what
+ * strcmp() in the reference's CMP_STR sees, including the run-on into the next
+ * field when strncpy left no terminator (buildEngine-serial.c:171).
+ * Distinct values are collected with an open-addressing hash set (one pass over
+ * the rows), only the distinct ones are sorted. */
 static int build_dictionary(record *const *rows, size_t n, size_t off, struct hipDictionary *d,
                             uint32_t *codes) {
-    const char **ptrs = malloc((n ? n : 1) * sizeof *ptrs);
-    if (!ptrs) return -1;
-    for (size_t i = 0; i < n; i++) ptrs[i] = (const char *)rows[i] + off;
-    qsort(ptrs, n, sizeof *ptrs, cmp_cstr_ptr);
+    size_t cap = 1024;
+    while (cap < 2 * n + 16 && cap < ((size_t)1 << 31)) cap <<= 1;
+    uint32_t *slot = malloc(cap * sizeof *slot);                /* distinct id + 1, 0 = empty */
+    const char **first = malloc((n ? n : 1) * sizeof *first);   /* representative of each distinct id */
+    if (!slot || !first) { free(slot); free(first); return -1; }
+    memset(slot, 0, cap * sizeof *slot);
     size_t distinct = 0, bytes = 0;
     for (size_t i = 0; i < n; i++) {
-        if (i == 0 || strcmp(ptrs[i], ptrs[distinct - 1]) != 0) {
-            ptrs[distinct++] = ptrs[i];
-            bytes += strlen(ptrs[i]) + 1;
+        const char *s = (const char *)rows[i] + off;
+        size_t h = (size_t)hash_cstr(s) & (cap - 1);
+        for (;;) {
+            const uint32_t v = slot[h];
+            if (v == 0) {
+                first[distinct] = s;
+                bytes += strlen(s) + 1;
+                slot[h] = (uint32_t)++distinct;
+                codes[i] = (uint32_t)distinct - 1;
+                break;
+            }
+            if (strcmp(first[v - 1], s) == 0) { codes[i] = v - 1; break; }
+            h = (h + 1) & (cap - 1);
         }
     }
+    free(slot);
+    /* rank of every distinct id in strcmp order */
+    const char ***order = malloc((distinct ? distinct : 1) * sizeof *order);
+    uint32_t *rank = malloc((distinct ? distinct : 1) * sizeof *rank);
     d->count = (int)distinct;
     d->storage = malloc(bytes ? bytes : 1);
+    d->storage_bytes = bytes;
     d->values = malloc((distinct ? distinct : 1) * sizeof *d->values);
-    if (!d->storage || !d->values) { free(ptrs); return -1; }
+    if (!order || !rank || !d->storage || !d->values) { free(first); free(order); free(rank); return -1; }
+    for (size_t k = 0; k < distinct; k++) order[k] = &first[k];
+    qsort(order, distinct, sizeof *order, cmp_cstr_ptr_ptr);
     char *w = d->storage;
-    for (size_t i = 0; i < distinct; i++) {
-        const size_t len = strlen(ptrs[i]) + 1;
-        memcpy(w, ptrs[i], len);
-        d->values[i] = w;
-        w += len;
+    for (size_t r = 0; r < distinct; r++) {
+        const size_t id = (size_t)(order[r] - first);
+        rank[id] = (uint32_t)r;
+        const size_t l = strlen(first[id]) + 1;
+        memcpy(w, first[id], l);
+        d->values[r] = w;
+        w += l;
     }
-    free(ptrs);
-    for (size_t i = 0; i < n; i++) {
-        const char *s = (const char *)rows[i] + off;
-        size_t l = 0, r = distinct;
-        while (l < r) { size_t m = l + (r - l) / 2; if (strcmp(d->values[m], s) < 0) l = m + 1; else r = m; }
-        codes[i] = (uint32_t)l;
-    }
+    for (size_t i = 0; i < n; i++) codes[i] = rank[codes[i]];
+    free(order); free(rank); free(first);
     return 0;
 }
 
@@ -197,68 +286,110 @@ void hipSchemaOfTable(const struct hipTable *t, struct hipSchema *s) {
     }
 }
 
-/* Builds a device table from `n` host rows.  ctx may be shared (owned by the caller). */
-struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) {
-    struct hipTable *t = calloc(1, sizeof *t);
-    if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
-    t->ctx = ctx;
-    t->n_rows = n;
-    t->capacity_rows = (n + PQPS_TILE_ROWS - 1) / PQPS_TILE_ROWS * PQPS_TILE_ROWS;
-    if (t->capacity_rows == 0) t->capacity_rows = PQPS_TILE_ROWS;
-    uint32_t *codes = malloc((n ? n : 1) * sizeof *codes);
-    void *stage = malloc(t->capacity_rows * 8);
-    if (!codes || !stage) { perror("Failed to allocate staging memory"); exit(EXIT_FAILURE); }
+/* One column: gather the field of every row into its staging buffer (dictionary
+ * columns: build the dictionary first).  Columns are independent -> one thread each. */
+struct col_job { record *const *rows; size_t n, cap_rows; struct hipTable *t; void *stage[HIPCOL_COUNT]; int failed; };
 
-    for (int c = 0; c < HIPCOL_COUNT; c++) {
-        uint32_t width;
-        memset(stage, 0, t->capacity_rows * 8);
+static void stage_columns(void *arg, size_t begin, size_t end) {
+    struct col_job *j = arg;
+    const size_t n = j->n;
+    for (size_t c = begin; c < end; c++) {
+        void *stage = j->stage[c];
         switch (k_kind[c]) {
         case HIPKIND_U64:
-            width = 8;
-            for (size_t i = 0; i < n; i++) ((uint64_t *)stage)[i] = *(const uint64_t *)((const char *)rows[i] + k_offset[c]);
+            j->t->col[c].width = 8;
+            for (size_t i = 0; i < n; i++) ((uint64_t *)stage)[i] = *(const uint64_t *)((const char *)j->rows[i] + k_offset[c]);
             break;
         case HIPKIND_I32:
-            width = 4;
-            for (size_t i = 0; i < n; i++) ((int32_t *)stage)[i] = *(const int *)((const char *)rows[i] + k_offset[c]);
+            j->t->col[c].width = 4;
+            for (size_t i = 0; i < n; i++) ((int32_t *)stage)[i] = *(const int *)((const char *)j->rows[i] + k_offset[c]);
             break;
         case HIPKIND_BOOL:
-            width = 1;
-            for (size_t i = 0; i < n; i++) ((uint8_t *)stage)[i] = *(const bool *)((const char *)rows[i] + k_offset[c]) ? 1 : 0;
+            j->t->col[c].width = 1;
+            for (size_t i = 0; i < n; i++) ((uint8_t *)stage)[i] = *(const bool *)((const char *)j->rows[i] + k_offset[c]) ? 1 : 0;
             break;
-        default:
-            if (build_dictionary(rows, n, k_offset[c], &t->dict[c], codes) != 0) {
-                perror("Failed to build dictionary");
-                exit(EXIT_FAILURE);
-            }
-            width = t->dict[c].count <= 256 ? 1 : t->dict[c].count <= 65536 ? 2 : 4;
+        default: {
+            uint32_t *codes = malloc((n ? n : 1) * sizeof *codes);
+            if (!codes || build_dictionary(j->rows, n, k_offset[c], &j->t->dict[c], codes) != 0) { j->failed = 1; free(codes); break; }
+            const uint32_t width = j->t->dict[c].count <= 256 ? 1 : j->t->dict[c].count <= 65536 ? 2 : 4;
+            j->t->col[c].width = width;
             for (size_t i = 0; i < n; i++) {
                 if (width == 1) ((uint8_t *)stage)[i] = (uint8_t)codes[i];
                 else if (width == 2) ((uint16_t *)stage)[i] = (uint16_t)codes[i];
                 else ((uint32_t *)stage)[i] = codes[i];
             }
+            free(codes);
             break;
         }
+        }
+    }
+}
+
+static void *col_thread(void *p) {
+    struct par_task *t = p;
+    t->fn(t->arg, t->begin, t->end);
+    return NULL;
+}
+
+/* Builds a device table from `n` host rows.  ctx may be shared (owned by the caller).
+ * Capacity leaves head-room so that INSERT appends in place. */
+struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) {
+    struct hipTable *t = calloc(1, sizeof *t);
+    if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+    t->ctx = ctx;
+    t->n_rows = n;
+    t->capacity_rows = (n + n / 16 + PQPS_TILE_ROWS) / PQPS_TILE_ROWS * PQPS_TILE_ROWS;
+    struct col_job job;
+    memset(&job, 0, sizeof job);
+    job.rows = rows; job.n = n; job.cap_rows = t->capacity_rows; job.t = t;
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        job.stage[c] = calloc(t->capacity_rows, 8);
+        if (!job.stage[c]) { perror("Failed to allocate staging memory"); exit(EXIT_FAILURE); }
+    }
+    /* one thread per column (12 independent tasks); tiny tables stay on the caller's thread */
+    if (n < 4096 || host_threads() == 1) {
+        stage_columns(&job, 0, HIPCOL_COUNT);
+    } else {
+        pthread_t tid[HIPCOL_COUNT];
+        struct par_task task[HIPCOL_COUNT];
+        for (int c = 0; c < HIPCOL_COUNT; c++) {
+            task[c].fn = stage_columns; task[c].arg = &job; task[c].begin = (size_t)c; task[c].end = (size_t)c + 1;
+            if (pthread_create(&tid[c], NULL, col_thread, &task[c]) != 0) { stage_columns(&job, (size_t)c, (size_t)c + 1); tid[c] = 0; }
+        }
+        for (int c = 0; c < HIPCOL_COUNT; c++) if (tid[c]) pthread_join(tid[c], NULL);
+    }
+    if (job.failed) { perror("Failed to build dictionary"); exit(EXIT_FAILURE); }
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        const uint32_t width = t->col[c].width;
         void *dev = NULL;
         if (pqps_malloc(ctx, t->capacity_rows * width, &dev) != PQPS_OK) hip_die("column allocation");
-        if (pqps_upload(ctx, dev, stage, t->capacity_rows * width, NULL) != PQPS_OK) hip_die("column upload");
+        if (pqps_upload(ctx, dev, job.stage[c], t->capacity_rows * width, NULL) != PQPS_OK) hip_die("column upload");
         t->col[c].data = dev;
-        t->col[c].width = width;
+        free(job.stage[c]);
     }
-    free(stage);
-    free(codes);
-
     t->capacity_ids = t->capacity_rows;
     if (pqps_malloc(ctx, t->capacity_ids * sizeof(uint32_t), (void **)&t->ids_dev) != PQPS_OK) hip_die("result allocation");
     if (pqps_malloc(ctx, 8 * sizeof(uint64_t), (void **)&t->count_dev) != PQPS_OK) hip_die("counter allocation");
     return t;
 }
 
+static void dictionary_free(struct hipDictionary *d) {
+    if (d->values) {
+        for (int i = 0; i < d->count; i++) {                    /* values appended by INSERT live outside `storage` */
+            const char *v = d->values[i];
+            if (!(v >= d->storage && v < d->storage + d->storage_bytes)) free((void *)v);
+        }
+    }
+    free(d->values);
+    free(d->storage);
+    memset(d, 0, sizeof *d);
+}
+
 void hipTableFree(struct hipTable *t, int n_indexes) {
     if (!t) return;
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         if (t->col[c].data) pqps_free(t->ctx, (void *)t->col[c].data);
-        free(t->dict[c].values);
-        free(t->dict[c].storage);
+        dictionary_free(&t->dict[c]);
     }
     if (t->index) {
         for (int i = 0; i < n_indexes; i++) {
@@ -315,6 +446,7 @@ bool buildDeviceTableHIP(struct engineS *engine) {
     if (pqps_ctx_create(device, &ctx) != PQPS_OK) hip_die("cannot create a device context");
     struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
     t->row_block = engine->record_block;               /* block handed over by getAllRecordsFromFileHIP */
+    t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 1);
     engine->record_block = t;
     return true;
 }
@@ -324,14 +456,79 @@ void rebuildDeviceTableHIP(struct engineS *engine) {
     struct hipTable *old = engine->record_block;
     pqps_ctx *ctx = old->ctx;
     record *block = old->row_block;
+    const size_t row_capacity = old->row_capacity;
     hipTableFree(old, engine->num_indexes);
     struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
     t->row_block = block;
+    t->row_capacity = row_capacity;
     engine->record_block = t;
     if (engine->num_indexes > 0) {
         t->index = calloc((size_t)engine->num_indexes, sizeof *t->index);
         for (int i = 0; i < engine->num_indexes; i++) build_index(engine, t, i);
     }
+}
+
+/* Rebuilds every device index (a device radix sort each; cheap next to a table rebuild). */
+static void rebuild_indexes(struct engineS *engine, struct hipTable *t) {
+    for (int i = 0; i < engine->num_indexes; i++) {
+        if (t->index[i].perm_dev) pqps_free(t->ctx, t->index[i].perm_dev);
+        if (t->index[i].keys_dev) pqps_free(t->ctx, t->index[i].keys_dev);
+        build_index(engine, t, i);
+    }
+}
+
+/* INSERT: appends the last host row (engine->all_records[n-1]) to the device columns in place.
+ * A string value that is new to its dictionary is inserted at its rank and the codes at or
+ * above that rank are bumped on the device (order-preserving codes stay order-preserving).
+ * Falls back to a full rebuild only when a column has to change its code width or the
+ * head-room is used up. */
+void appendRowDeviceTableHIP(struct engineS *engine) {
+    struct hipTable *t = engine->record_block;
+    const size_t n = (size_t)engine->num_records;               /* rows after the insert */
+    if (n == 0 || n - 1 != t->n_rows || n > t->capacity_rows) { rebuildDeviceTableHIP(engine); return; }
+    const record *r = engine->all_records[n - 1];
+    /* first pass: would any dictionary outgrow its code width? */
+    int pos[HIPCOL_COUNT], present[HIPCOL_COUNT];
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        if (k_kind[c] != HIPKIND_DICT) continue;
+        struct hipDictionary *d = &t->dict[c];
+        const char *s = (const char *)r + k_offset[c];
+        int l = 0, h = d->count;
+        while (l < h) { const int m = l + (h - l) / 2; if (strcmp(d->values[m], s) < 0) l = m + 1; else h = m; }
+        pos[c] = l;
+        present[c] = l < d->count && strcmp(d->values[l], s) == 0;
+        const uint64_t limit = t->col[c].width == 1 ? 256 : t->col[c].width == 2 ? 65536 : 0xFFFFFFFFull;
+        if (!present[c] && (uint64_t)d->count + 1 > limit) { rebuildDeviceTableHIP(engine); return; }
+    }
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        const uint32_t w = t->col[c].width;
+        uint64_t value = 0;
+        const char *p = (const char *)r + k_offset[c];
+        switch (k_kind[c]) {
+        case HIPKIND_U64: value = *(const uint64_t *)p; break;
+        case HIPKIND_I32: value = (uint32_t)*(const int *)p; break;
+        case HIPKIND_BOOL: value = *(const bool *)p ? 1 : 0; break;
+        default: {
+            struct hipDictionary *d = &t->dict[c];
+            if (!present[c]) {
+                const char **grown = realloc(d->values, ((size_t)d->count + 1) * sizeof *grown);
+                char *copy = strdup(p);
+                if (!grown || !copy) { perror("Failed to grow dictionary"); exit(EXIT_FAILURE); }
+                d->values = grown;
+                memmove(&d->values[pos[c] + 1], &d->values[pos[c]], ((size_t)d->count - (size_t)pos[c]) * sizeof *grown);
+                d->values[pos[c]] = copy;
+                d->count++;
+                if (pqps_bump_codes(t->ctx, (void *)t->col[c].data, w, t->n_rows, (uint32_t)pos[c], NULL) != PQPS_OK)
+                    hip_die("dictionary code shift");
+            }
+            value = (uint64_t)pos[c];
+            break;
+        }
+        }
+        if (pqps_upload(t->ctx, (char *)t->col[c].data + (n - 1) * w, &value, w, NULL) != PQPS_OK) hip_die("row upload");
+    }
+    t->n_rows = n;
+    rebuild_indexes(engine, t);
 }
 
 void destroyDeviceTableHIP(struct engineS *engine) {

@@ -344,15 +344,21 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
 
     struct hipTable *t = engine->record_block;
     const size_t n = (size_t)engine->num_records;
-    record *block = realloc(t->row_block, (n + 1) * sizeof *block);
-    record **rows = realloc(engine->all_records, (n + 1) * sizeof *rows);
-    if (!block || !rows) return false;
-    block[n] = *r;
-    for (size_t i = 0; i <= n; i++) rows[i] = &block[i];
-    t->row_block = block;
-    engine->all_records = rows;
+    /* host row store grows geometrically; all_records[] is re-pointed only when the block moved */
+    if (n + 1 > t->row_capacity) {
+        const size_t cap = n + n / 8 + 64;
+        record *block = realloc(t->row_block, cap * sizeof *block);
+        record **rows = realloc(engine->all_records, cap * sizeof *rows);
+        if (!block || !rows) return false;
+        if (block != t->row_block) for (size_t i = 0; i < n; i++) rows[i] = &block[i];
+        t->row_block = block;
+        t->row_capacity = cap;
+        engine->all_records = rows;
+    }
+    t->row_block[n] = *r;
+    engine->all_records[n] = &t->row_block[n];
     engine->num_records = (int)(n + 1);
-    rebuildDeviceTableHIP(engine);
+    appendRowDeviceTableHIP(engine);
     return true;
 }
 

@@ -267,7 +267,7 @@ def test_engine_index_order_matches_reference_btree(ctx):
 
 
 class HipDictionary(C.Structure):
-    _fields_ = [("count", C.c_int), ("values", C.c_void_p), ("storage", C.c_void_p)]
+    _fields_ = [("count", C.c_int), ("values", C.c_void_p), ("storage", C.c_void_p), ("storage_bytes", C.c_size_t)]
 
 
 class HipIndex(C.Structure):
@@ -278,7 +278,7 @@ class HipTable(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("n_rows", C.c_uint64), ("capacity_rows", C.c_uint64),
                 ("col", pq.Column * 12), ("dict", HipDictionary * 12), ("index", C.POINTER(HipIndex)),
                 ("ids_dev", C.c_void_p), ("capacity_ids", C.c_uint64), ("count_dev", C.c_void_p),
-                ("row_block", C.c_void_p)]
+                ("row_block", C.c_void_p), ("row_capacity", C.c_size_t)]
 
 
 def test_kat_reference_unit_tests():
