@@ -36,6 +36,8 @@ QUERIES = {
     "Q_B": ([("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")], "sudo_used = TRUE AND risk_level > 2"),
     "Q_C": ([("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1500"), "OR", ("risk_level", "=", "5")],
             "exit_code != 0 AND user_id >= 1500 OR risk_level = 5"),
+    "Q_u8": ([("sudo_used", "=", "TRUE")], "sudo_used = TRUE"),
+    "Q_u16": ([("user_name", "=", "student1030")], 'user_name = "student1030"'),
 }
 
 

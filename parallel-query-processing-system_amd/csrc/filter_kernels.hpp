@@ -53,6 +53,8 @@ struct EvalArgs {
     uint32_t n_cols;
     uint32_t n_leaves;
     uint32_t negmask;
+    uint32_t chain;                  // 0: general tree; 1: AND of leaves; 2: NOT(AND) = OR form (spec kernels)
+    uint32_t chain_want;             // bit k: raw window hit that leaf slot k must have inside the AND
     uint32_t pad0;
     uint8_t width_log2[PQPS_MAX_COLUMNS];
     uint8_t leaf_begin[PQPS_MAX_COLUMNS + 1];   // leaves of column c: [leaf_begin[c], leaf_begin[c+1])
@@ -217,22 +219,25 @@ __device__ __forceinline__ uint32_t combine_masks(const EvalArgs &a, const LeafM
 
 // ---- per-step output ---------------------------------------------------------------
 // Bit p of a lane's 16 match bits <-> row  step_row0 + (p / RPL) * 64 * RPL + lane * RPL + p % RPL.
+// 128 B of match bits of one step: the 16-bit words of 8 neighbouring lanes are gathered into
+// one lane (DPP), 8 lanes store 16 B each.
+__device__ __forceinline__ void store_mask(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t lane) {
+    const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // lane pairs (even lanes valid)
+    const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lane+2's pair
+    const uint32_t q0 = w2, q1 = w2b;                                              // lanes 0 mod 4: words 0..3
+    const uint32_t q2 = dpp_or_zero<0x104>(q0), q3 = dpp_or_zero<0x104>(q1);       // row_shl:4 -> lane+4's words
+    if ((lane & 7u) == 0) {
+        uint4 v; v.x = q0; v.y = q1; v.z = q2; v.w = q3;
+        *(uint4 *)(a.masks + step * 64 + lane) = v;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t rpl_log2,
                                           uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
     const uint32_t cnt = wave_sum_u32(__popc(mbits));
     if (MODE == MODE_IDS) {
-        if (cnt) {                                               // 128 B per step, only if needed
-            // gather the 16-bit words of 8 neighbouring lanes into one lane -> 8 lanes store 16 B each
-            const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // lane pairs (even lanes valid)
-            const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lane+2's pair
-            const uint32_t q0 = w2, q1 = w2b;                                              // lanes 0 mod 4: words 0..3
-            const uint32_t q2 = dpp_or_zero<0x104>(q0), q3 = dpp_or_zero<0x104>(q1);       // row_shl:4 -> lane+4's words
-            if ((lane & 7u) == 0) {
-                uint4 v; v.x = q0; v.y = q1; v.z = q2; v.w = q3;
-                *(uint4 *)(a.masks + step * 64 + lane) = v;
-            }
-        }
+        if (cnt) store_mask(a, step, mbits, lane);               // 128 B per step, only if needed
         if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
     } else {
         wave_total += cnt;
@@ -241,6 +246,77 @@ __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint
             for (uint32_t p = 0; p < 16; p++) {
                 const uint64_t row = step * kStepRows + (uint64_t)(p >> rpl_log2) * 64 * rpl + lane * rpl + (p & (rpl - 1));
                 if (row < n_rows) a.out_flags[row] = (uint8_t)((mbits >> p) & 1u);
+            }
+        }
+    }
+}
+
+// ---- chain path: the predicate is an AND of (possibly complemented) leaves, or its negation ----
+// Every leaf-row compare writes its 64-lane result straight into an SGPR pair (one VALU, SDWA
+// picks the byte / halfword); AND-ing the leaves and counting the matches is scalar-unit work;
+// per-lane match bits are only materialised for steps that contain a match.
+struct RowPlanes { uint64_t p[16]; };                           // p[r] bit l = row r of lane l
+
+template <typename T>
+__device__ __forceinline__ void chain_leaf(const T (&v)[16], T lo, T span, bool want, RowPlanes &acc) {
+    // `want`: the raw window hit this leaf needs; the four branches are wave-uniform
+    if (span == 0) {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] == lo);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] != lo);
+        }
+    } else if (lo == 0) {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] <= span);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] > span);
+        }
+    } else {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot((T)(v[r] - lo) <= span);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot((T)(v[r] - lo) > span);
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void emit_planes(const EvalArgs &a, uint64_t step, RowPlanes &acc, uint32_t rpl_log2,
+                                            uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
+    if (a.chain == 2) {                                         // OR form: NOT of the AND
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc.p[r] = ~acc.p[r];
+    }
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) any |= acc.p[r];
+    uint32_t cnt = 0;
+    if (any) {                                                  // uniform
+#pragma unroll
+        for (int r = 0; r < 16; r++) cnt += (uint32_t)__popcll(acc.p[r]);
+    }
+    if (MODE == MODE_IDS) {
+        if (cnt) {
+            uint32_t mbits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) mbits |= __builtin_amdgcn_inverse_ballot_w64(acc.p[r]) ? (1u << r) : 0u;
+            store_mask(a, step, mbits, lane);
+        }
+        if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
+    } else {
+        wave_total += cnt;
+        if (MODE == MODE_FLAGS) {                               // not used by the spec kernels; kept for completeness
+            const uint32_t rpl = 1u << rpl_log2;
+            for (uint32_t p = 0; p < 16; p++) {
+                const uint64_t row = step * kStepRows + (uint64_t)(p >> rpl_log2) * 64 * rpl + lane * rpl + (p & (rpl - 1));
+                if (row < n_rows) a.out_flags[row] = (uint8_t)((acc.p[p] >> lane) & 1ull);
             }
         }
     }
@@ -453,6 +529,21 @@ __device__ __forceinline__ void eval_col_masks(const EvalArgs &a, int slot, cons
 }
 
 template <int W, int RPL, int U>
+__device__ __forceinline__ void eval_col_chain(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, RowPlanes &acc) {
+    const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
+    if constexpr (W == 8) {
+        uint64_t v[16];
+        unpack64(raw, v, std::make_integer_sequence<int, 16>{});
+        for (uint32_t k = kb; k < ke; k++) chain_leaf<uint64_t>(v, a.lo[k], a.span[k], (a.chain_want >> k) & 1u, acc);
+    } else {
+        uint32_t v[16];
+        unpack32(raw, v, std::make_integer_sequence<int, 16>{});
+        for (uint32_t k = kb; k < ke; k++)
+            chain_leaf<uint32_t>(v, (uint32_t)a.lo[k], (uint32_t)a.span[k], (a.chain_want >> k) & 1u, acc);
+    }
+}
+
+template <int W, int RPL, int U>
 __device__ __forceinline__ void eval_col(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&idx)[16]) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
@@ -479,36 +570,32 @@ struct RawStep {
         if constexpr (W1 != 0) r1.load(a.col[1], lane_row0);
         if constexpr (W2 != 0) r2.load(a.col[2], lane_row0);
     }
-    __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {
-        if (a.n_leaves <= PQPS_TT_LEAVES) {                     // uniform: row-mask path
-            LeafMasks lm;
+    __device__ __forceinline__ void eval_chain(const EvalArgs &a, RowPlanes &acc) const {
 #pragma unroll
-            for (int k = 0; k < PQPS_TT_LEAVES; k++) lm.m[k] = 0;
-            eval_col_masks<W0, RPL, U>(a, 0, r0, lm);
-            if constexpr (W1 != 0) eval_col_masks<W1, RPL, U>(a, 1, r1, lm);
-            if constexpr (W2 != 0) eval_col_masks<W2, RPL, U>(a, 2, r2, lm);
-            return combine_masks(a, lm, 0xFFFFu);
-        }
-        uint32_t idx[16];
+        for (int r = 0; r < 16; r++) acc.p[r] = ~0ull;
+        eval_col_chain<W0, RPL, U>(a, 0, r0, acc);
+        if constexpr (W1 != 0) eval_col_chain<W1, RPL, U>(a, 1, r1, acc);
+        if constexpr (W2 != 0) eval_col_chain<W2, RPL, U>(a, 2, r2, acc);
+    }
+    __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {     // <= 6 leaves: row-mask path
+        LeafMasks lm;
 #pragma unroll
-        for (int r = 0; r < 16; r++) idx[r] = 0;
-        eval_col<W0, RPL, U>(a, 0, r0, idx);
-        if constexpr (W1 != 0) eval_col<W1, RPL, U>(a, 1, r1, idx);
-        if constexpr (W2 != 0) eval_col<W2, RPL, U>(a, 2, r2, idx);
-        return combine_leaves<16>(a, idx);
+        for (int k = 0; k < PQPS_TT_LEAVES; k++) lm.m[k] = 0;
+        eval_col_masks<W0, RPL, U>(a, 0, r0, lm);
+        if constexpr (W1 != 0) eval_col_masks<W1, RPL, U>(a, 1, r1, lm);
+        if constexpr (W2 != 0) eval_col_masks<W2, RPL, U>(a, 2, r2, lm);
+        return combine_masks(a, lm, 0xFFFFu);
     }
 };
 
 // W0 >= W1 >= W2 are the byte widths of the predicate columns (0 = slot unused).
+// General tree of <= 6 leaves (row-mask path), one step per iteration.
 template <int MODE, int W0, int W1, int W2>
 __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;                                 // chunks per step
-    // narrow shapes keep few bytes in flight per wave: double-buffer their loads (the
-    // next step is requested before the current one is evaluated)
-    constexpr bool PREFETCH = false;       // measured: the extra registers cost more occupancy than the overlap wins
     clear_super_sums<MODE>(a);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -517,29 +604,53 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
     uint64_t wave_total = 0;
-
-    if constexpr (PREFETCH) {
-        RawStep<W0, W1, W2, RPL, U> A, B;
-        uint64_t step = wave;
-        if (step < full_steps) A.load(a, step * kStepRows + lane_off);
-        while (step < full_steps) {
-            const uint64_t s1 = step + n_waves;
-            if (s1 < full_steps) B.load(a, s1 * kStepRows + lane_off);
-            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
-            if (s1 >= full_steps) break;
-            const uint64_t s2 = s1 + n_waves;
-            if (s2 < full_steps) A.load(a, s2 * kStepRows + lane_off);
-            emit_step<MODE>(a, s1, B.eval(a), log2i(RPL), n_rows, lane, wave_total);
-            step = s2;
-        }
-    } else {
-        for (uint64_t step = wave; step < full_steps; step += n_waves) {
-            RawStep<W0, W1, W2, RPL, U> A;
-            A.load(a, step * kStepRows + lane_off);
-            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
-        }
+    for (uint64_t step = wave; step < full_steps; step += n_waves) {
+        RawStep<W0, W1, W2, RPL, U> A;
+        A.load(a, step * kStepRows + lane_off);
+        emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
     }
     // the partial last step (if any) goes through the guarded evaluator, RPL = 4 layout
+    if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
+        const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
+        emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
+    }
+    finish_totals<MODE>(a, wave_total);
+}
+
+// Chain predicates (AND of possibly complemented leaves, or the negation of one): SGPR planes.
+// A wave keeps the loads of S steps in flight (all S x columns loads are issued, then the steps
+// are evaluated one after the other): >= 4 KB per wave even for 1-byte columns -- HBM latency x
+// bandwidth needs > 100 KB in flight per CU.
+constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 >= 4 ? 1 : (w0 + w1 + w2 >= 2 ? 2 : 4); }
+
+template <int MODE, int W0, int W1, int W2, int S>
+__global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
+    constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
+    constexpr int U = 16 / RPL;
+    clear_super_sums<MODE>(a);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint64_t n_rows = a.n_rows;
+    const uint64_t full_steps = n_rows / kStepRows;
+    const uint64_t lane_off = lane * RPL;
+    uint64_t wave_total = 0;
+    RawStep<W0, W1, W2, RPL, U> A[S];
+    for (uint64_t step0 = wave; step0 < full_steps; step0 += n_waves * S) {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const uint64_t step = step0 + (uint64_t)i * n_waves;
+            if (step < full_steps) A[i].load(a, step * kStepRows + lane_off);      // uniform guard
+        }
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const uint64_t step = step0 + (uint64_t)i * n_waves;
+            if (step >= full_steps) break;
+            RowPlanes acc;
+            A[i].eval_chain(a, acc);
+            emit_planes<MODE>(a, step, acc, log2i(RPL), n_rows, lane, wave_total);
+        }
+    }
     if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
         const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
         emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);

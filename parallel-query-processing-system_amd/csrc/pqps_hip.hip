@@ -293,6 +293,21 @@ void fill_args(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, const pqps
         a.on_false[i] = pred->on_false[i];
         a.order[i] = pred->order[i];
     }
+    // Chain form: the truth table has exactly one true row  (AND of leaves, each required to be the
+    // bit of that row) or exactly one false row (the negation of such an AND, i.e. an OR form).
+    const uint32_t n = pred->n_leaves;
+    if (n >= 1 && n <= PQPS_TT_LEAVES) {
+        const uint32_t rows = 1u << n;
+        const uint64_t all = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+        const uint64_t tt = pred->truth & all;
+        uint64_t single = 0;
+        if (__builtin_popcountll(tt) == 1) { a.chain = 1; single = tt; }
+        else if (__builtin_popcountll(tt) == (int)rows - 1) { a.chain = 2; single = ~tt & all; }
+        if (a.chain) {
+            const uint32_t e = (uint32_t)__builtin_ctzll(single);   // leaf k must evaluate to bit k of e
+            a.chain_want = (e ^ a.negmask) & (rows >= 64 ? 0x3Fu : ((1u << n) - 1u));   // ... as a raw window hit
+        }
+    }
 }
 
 // ---- K1 dispatch: width-specialised instantiations ----------------------------------------
@@ -305,19 +320,25 @@ typedef void (*eval_fn)(const EvalArgs);
     X(8,8,8) X(8,8,4) X(8,8,2) X(8,8,1) X(8,4,4) X(8,4,2) X(8,4,1) X(8,2,2) X(8,2,1) X(8,1,1) \
     X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
 
+// chain kernels exist with 1 step per iteration and (narrow shapes) with several
 template <int MODE>
-eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2) {
-#define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return eval_spec_kernel<MODE, A, B, C>;
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step) {
+#define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return !chain ? eval_spec_kernel<MODE, A, B, C> \
+        : (multi_step ? eval_chain_kernel<MODE, A, B, C, chain_steps(A, B, C)> : eval_chain_kernel<MODE, A, B, C, 1>);
     PQPS_FOR_EACH_SHAPE(X)
 #undef X
     return nullptr;
 }
 
+// `a` must already carry the chain classification of fill_args().
 template <int MODE>
-eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
-    if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1) {
+eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred, const EvalArgs &a, uint64_t n_rows) {
+    if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1 && pred->n_leaves <= PQPS_TT_LEAVES) {
         const uint32_t w0 = cols[0].width, w1 = n_cols > 1 ? cols[1].width : 0, w2 = n_cols > 2 ? cols[2].width : 0;
-        if (eval_fn f = find_spec<MODE>(w0, w1, w2)) return f;      // nullptr unless widths are non-increasing
+        // several steps per iteration pay off once a wave has many steps to stream
+        static const char *force = getenv("PQPS_CHAIN_MULTI");
+        const bool multi = force ? atoi(force) != 0 : n_rows >= (1ull << 28);
+        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi)) return f;   // nullptr unless widths are non-increasing
     }
     return eval_generic_kernel<MODE, false>;
 }
@@ -537,7 +558,7 @@ int pqps_filter_scan(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    return run_filter(ctx, pick_eval<MODE_IDS>(cols, n_cols, pred), a, n_rows, MODE_IDS, false,
+    return run_filter(ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false,
                       id_base, out_ids, out_capacity, out_count, pick_stream(ctx, stream));
 }
 
@@ -550,7 +571,7 @@ int pqps_filter_count(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    return run_filter(ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred), a, n_rows, MODE_COUNT, false,
+    return run_filter(ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false,
                       0, nullptr, 0, out_count, s);
 }
 
