@@ -202,13 +202,15 @@ def main():
     torch.cuda.synchronize()
     local_matches = int(cal_cnt.item())
     max_matches = local_matches
+    cdev = device if args.backend == "nccl" else torch.device("cpu")      # where small control tensors live
     if world > 1:
-        mm = torch.tensor([local_matches], dtype=torch.int64, device=device)
+        mm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(mm, op=dist.ReduceOp.MAX)
         max_matches = int(mm.item())
     slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096
     del cal_ids
-    mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq) for _ in range(2)]
+    mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq,
+                           host_staged=(args.backend != "nccl")) for _ in range(2)]
     comm = torch.cuda.Stream(device=device)
     filt_done = [torch.cuda.Event() for _ in range(2)]
     merge_done = [torch.cuda.Event() for _ in range(2)]
@@ -253,7 +255,7 @@ def main():
     ctx.set_timing(False)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -266,7 +268,7 @@ def main():
         merged = last.result()
         import numpy as np
         assert len(merged) > 0 and bool(np.all(merged[1:] > merged[:-1])), "merged IDs are not strictly ascending"
-        tm = torch.tensor([local_matches], dtype=torch.int64, device=device)
+        tm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(tm)
         total_matches = int(tm.item())
         assert len(merged) == total_matches, (len(merged), total_matches)

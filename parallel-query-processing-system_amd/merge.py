@@ -35,8 +35,11 @@ class IdMerger:
     ids_local / count_local are written by pqps_filter_scan; after merge(),
     `merged[:totals[0]]` on EVERY rank holds the global ascending ID list."""
 
-    def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None):
+    def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False):
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        # host_staged: collectives run on CPU copies (gloo rehearsal of the GPU control flow on a
+        # box where RCCL cannot be used, e.g. several ranks sharing one device); never the fast path
+        self.host_staged = host_staged
         self.cap = int(slot_capacity)
         self.device = device
         self.ctx, self.pq = ctx, pq
@@ -54,6 +57,14 @@ class IdMerger:
         if self.world == 1:
             self.counts.copy_(self.count_local)
             self.slots.copy_(self.ids_local)
+        elif self.host_staged:
+            c_loc, i_loc = self.count_local.cpu(), self.ids_local.cpu()
+            c_all = [t.zeros_like(c_loc) for _ in range(self.world)]
+            i_all = [t.zeros_like(i_loc) for _ in range(self.world)]
+            dist.all_gather(c_all, c_loc)
+            dist.all_gather(i_all, i_loc)
+            self.counts.copy_(t.cat(c_all))
+            self.slots.copy_(t.cat(i_all))
         else:
             dist.all_gather_into_tensor(self.counts, self.count_local)           # mpi:753
             dist.all_gather_into_tensor(self.slots, self.ids_local)              # mpi:765 (equal-size slots)
