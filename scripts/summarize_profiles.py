@@ -36,14 +36,21 @@ def main():
     rnd, tags = sys.argv[1], sys.argv[2:]
     OUT.mkdir(exist_ok=True)
     for tag in tags:
-        for f in glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}" / "**" / "*_kernel_stats.csv"), recursive=True):
-            shutil.copy(f, OUT / f"{rnd}_{tag}_kernel_stats.csv")
+        import os
+        stats = glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}" / "**" / "*_kernel_stats.csv"), recursive=True)
+        if stats:
+            shutil.copy(max(stats, key=os.path.getmtime), OUT / f"{rnd}_{tag}_kernel_stats.csv")
             print("kernel stats ->", OUT / f"{rnd}_{tag}_kernel_stats.csv")
         bench = ROOT / "gpurun_out" / f"prof_{tag}.json"
         if bench.exists():
             shutil.copy(bench, OUT / f"{rnd}_{tag}_bench_under_rocprof.json")
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for f in glob.glob(str(ROOT / "gpurun_out" / f"pmc_{tag}_*" / "**" / "*_counter_collection.csv"), recursive=True):
+        import os
+        for d in glob.glob(str(ROOT / "gpurun_out" / f"pmc_{tag}_*")):
+            files = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+            if not files:
+                continue
+            f = max(files, key=os.path.getmtime)                 # newest run of this counter group only
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if k:
