@@ -135,6 +135,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary queries / read probe")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="N>1 exchange step: 'rccl' = the shim calls ncclAllGather itself (one host call per query); "
+                         "'torch' = torch.distributed collectives from Python (also the gloo rehearsal path)")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="N=1 rehearsal: run the N>1 exchange step (RCCL all-gather + merge, second stream) with a world of 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +147,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    # stdout carries exactly ONE line (the JSON): RCCL prints its version banner to fd 1 when the
+    # communicator comes up, so everything incidental is sent to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -155,8 +166,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    exchange = world > 1 or args.force_merge              # is there an exchange step after the scan?
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     pq, mg = load_pkg()
@@ -192,7 +205,7 @@ def main():
     pred, cols, nc, bytes_per_row = table.bind(chain)
     L = pq.lib()
 
-    # ---- result buffers (double-buffered for the merge pipeline) ---------------------------
+    # ---- result buffers (a ring of RING slots for the merge pipeline) ---------------------------
     # slot capacity from one calibration run of the same query (selectivity is a property of
     # the data, identical on every step); +25 % head-room, overflow is checked after timing
     cal_ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
@@ -209,28 +222,40 @@ def main():
         max_matches = int(mm.item())
     slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096
     del cal_ids
-    mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq,
-                           host_staged=(args.backend != "nccl")) for _ in range(2)]
-    comm = torch.cuda.Stream(device=device)
-    filt_done = [torch.cuda.Event() for _ in range(2)]
-    merge_done = [torch.cuda.Event() for _ in range(2)]
+    native = exchange and args.exchange == "rccl" and args.backend == "nccl"
+    xch, mergers = None, None
+    if native:
+        xch = mg.ShardExchange(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING)
+    else:
+        mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq,
+                               host_staged=(args.backend != "nccl"), always_collective=args.force_merge) for _ in range(RING)]
+        comm = torch.cuda.Stream(device=device)
+        filt_done = [torch.cuda.Event() for _ in range(RING)]
+        merge_done = [torch.cuda.Event() for _ in range(RING)]
 
     def step(k):
-        m = mergers[k & 1]
-        compute.wait_event(merge_done[k & 1])            # slot k&1 free again (no-op before first record)
-        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_local.data_ptr(), slot_cap,
-                                    m.count_local.data_ptr(), sptr), "pqps_filter_scan")
-        if world == 1:
+        r = k % RING
+        if native:
+            # scan on `compute`; all-gather + merge on the exchange's own stream, under the next scans
+            xch.select(cols, nc, count, start, C.byref(pred), r, sptr)
             return
-        filt_done[k & 1].record(compute)
+        m = mergers[r]
+        # slot r is free again once the merge that last used it (query k - RING) has finished: a host-side
+        # wait, normally already satisfied, so the scan stream carries no cross-stream barrier packet
+        merge_done[r].synchronize()
+        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap,
+                                    m.count_ptr, sptr), "pqps_filter_scan")
+        if not exchange:
+            return
+        filt_done[r].record(compute)
         with torch.cuda.stream(comm):
-            comm.wait_event(filt_done[k & 1])
+            comm.wait_event(filt_done[r])
             m.merge(stream_ptr=comm.cuda_stream)
-            merge_done[k & 1].record(comm)
+            merge_done[r].record(comm)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -241,8 +266,10 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    enqueued = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: {elapsed / max(args.steps, 1) * 1e6:.1f} us/step, host enqueue {enqueued / max(args.steps, 1) * 1e6:.1f} us/step")
     # ---- same K steps again with HIP events around every launch of the evaluate kernel (the
     # only kernel that reads the table) on its own stream: its average duration feeds
     # `roofline`.  Kept out of the timed region because an event record costs a few us of
@@ -260,12 +287,16 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- verify what the timed steps produced ------------------------------------------------
-    last = mergers[(args.steps - 1) & 1] if args.steps > 0 else mergers[0]
-    got_local = int(last.count_local.item())
+    last_slot = (args.steps - 1) % RING if args.steps > 0 else 0
+    if native:
+        merged, got_local = xch.result(last_slot)
+    else:
+        got_local = mergers[last_slot].local_count()
     assert got_local == local_matches, (got_local, local_matches)
     total_matches = local_matches
-    if world > 1:
-        merged = last.result()
+    if exchange:
+        if not native:
+            merged = mergers[last_slot].result()
         import numpy as np
         assert len(merged) > 0 and bool(np.all(merged[1:] > merged[:-1])), "merged IDs are not strictly ascending"
         tm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
@@ -289,11 +320,11 @@ def main():
                    "query": sql, "rows_per_gpu": args.rows, "rows_total": n_global,
                    "matches_total": total_matches, "selectivity": total_matches / n_global,
                    "bytes_per_row": bytes_per_row,
-                   "parallelism": f"row-range shards x{world}" + (", RCCL count+ID all-gather merge on every rank" if world > 1 else ""),
+                   "parallelism": f"row-range shards x{world}" + (f", one RCCL [count|IDs] all-gather + device merge per query on every rank ({'shim-driven' if native else 'torch.distributed'})" if exchange else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "eval_spec_kernel / eval_generic_kernel (K1: the only kernel that reads the table)",
+                     "kernel": K1_NAMES.get(args.query, "eval_spec_kernel / eval_generic_kernel") + " (K1: the only kernel that reads the table)",
                      "avg_kernel_ms": avg_kernel_ms, "avg_pipeline_ms": pipe_ms / max(launches, 1),
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
     }
@@ -302,11 +333,21 @@ def main():
         result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)
-    if world > 1:
+    if xch is not None:
+        xch.close()
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+RING = 4      # result slots in flight: query k's merge runs under the scans of queries k+1 ..
+
+# the K1 instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
+K1_NAMES = {"S1": "eval_chain_kernel<MODE_IDS, 2, 1, 0, STEPS>"}
 
 
 def pmc_traffic(query, rows):

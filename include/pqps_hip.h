@@ -163,16 +163,45 @@ int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int
                      uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
                      uint64_t *range, void *stream);
 
-/* Tail of the all-gatherv merge.  `segments` holds `world` equal-size slots of
- * `segment_capacity` u32 (what an equal-size RCCL all-gather delivered), slot r
- * carrying counts[r] ascending IDs; writes their rank-order concatenation to
- * `merged` -- the recvCounts / displs layout of MPI_Allgatherv
- * (engine/mpi/executeEngine-mpi.c:753-765) -- and, if `totals` != NULL,
- * totals[0] = IDs merged, totals[1] = sum of counts (larger => a slot overflowed).
- * Everything is device resident: no host round trip. */
-int pqps_merge_segments(pqps_ctx *ctx, const uint32_t *segments, const uint64_t *counts, uint32_t world,
-                        uint64_t segment_capacity, uint32_t *merged, uint64_t merged_capacity,
-                        uint64_t *totals, void *stream);
+/* Tail of the all-gatherv merge.  A slot is what one rank's pqps_filter_scan produced when
+ * given out_count = slot and out_ids = slot + PQPS_SLOT_HEADER_WORDS:
+ *     [u64 match count][u64 reserved][u32 row IDs ...]
+ * `slots` holds `world` such slots, `slot_stride` u32 apart -- what ONE equal-size RCCL
+ * all-gather delivers (the count travels with the payload, so MPI_Allgather of the sizes +
+ * MPI_Allgatherv of the data, engine/mpi/executeEngine-mpi.c:753-765, become a single
+ * collective).  Writes the rank-order concatenation of the ID lists to `merged` and, if
+ * `totals` != NULL, totals[0] = IDs merged, totals[1] = sum of the reported counts (larger
+ * => a slot overflowed).  Everything stays on the device. */
+#define PQPS_SLOT_HEADER_WORDS 4
+int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint64_t slot_stride,
+                     uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream);
+
+/* ---- multi-GPU SELECT: shard scan + ONE RCCL all-gather + device merge, one host call per query ----
+ * Replaces the exchange step of engine/mpi/executeEngine-mpi.c:717-768 (local scan of the rank's row
+ * range, MPI_Allgather of the sizes, MPI_Allgatherv of the payload).  One process per GPU; every rank
+ * makes the same calls in the same order.  RCCL is loaded at run time from `rccl_library` (e.g. the
+ * librccl.so of the process's torch build, or /opt/rocm/lib/librccl.so); the 128-byte id is produced on
+ * rank 0 and handed to the other ranks by whatever bootstrap the host has (torch.distributed broadcast,
+ * MPI_Bcast, a file).
+ *
+ * pqps_exchange_select(x, ..., slot, scan_stream) enqueues, without blocking on the device:
+ *   scan_stream     : the filter kernels, writing [count | IDs] into ring slot `slot`
+ *   exchange stream : (behind an event) ncclAllGather of the slot, pqps_merge_slots
+ * so query k's exchange runs under the scan of query k+1.  A slot may be reused after `ring` further
+ * calls; reuse waits on the host for the earlier merge.  pqps_exchange_result() waits for a slot's
+ * merge and returns the device pointer of the merged ascending ID list (identical on every rank),
+ * totals[0] = IDs merged, totals[1] = IDs reported; PQPS_EOVERFLOW if a rank's slot was too small. */
+typedef struct { char internal[128]; } pqps_rccl_id;     /* = ncclUniqueId */
+typedef struct pqps_exchange pqps_exchange;
+int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id);
+int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world,
+                         uint32_t rank, uint64_t slot_capacity, uint32_t ring, pqps_exchange **out);
+int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                         uint32_t id_base, const pqps_predicate *pred, uint32_t slot, void *scan_stream);
+int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
+                         uint64_t totals[2]);
+int pqps_exchange_sync(pqps_exchange *x);
+int pqps_exchange_destroy(pqps_exchange *x);
 
 /* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */
 void pqps_partition(uint64_t n_rows, int world, int rank, uint64_t *start, uint64_t *count);

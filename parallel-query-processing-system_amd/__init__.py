@@ -27,6 +27,7 @@ MAX_COLUMNS = 12
 MAX_LEAVES = 32
 TT_LEAVES = 6
 TILE_ROWS = 4096
+SLOT_HEADER_WORDS = 4
 ACCEPT, REJECT = 0xFE, 0xFF
 SYNTH_USERS = 2000
 
@@ -234,7 +235,13 @@ def lib():
     L.pqps_synth_generate_host.restype = None
     L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
     L.pqps_bump_codes.argtypes = [vp, vp, u32, u64, u32, vp]
-    L.pqps_merge_segments.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
+    L.pqps_merge_slots.argtypes = [vp, vp, u32, u64, vp, u64, vp, vp]
+    L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
+    L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]
+    L.pqps_exchange_select.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), u32, vp]
+    L.pqps_exchange_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.pqps_exchange_sync.argtypes = [vp]
+    L.pqps_exchange_destroy.argtypes = [vp]
     L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.hipColumnId.argtypes = [C.c_char_p]
     for name in ("hipDumpTokens", "hipDumpParse"):

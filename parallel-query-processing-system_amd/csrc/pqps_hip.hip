@@ -12,8 +12,10 @@
 #include <cstring>
 #include <new>
 #include <utility>
+#include <dlfcn.h>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>   // index build only (stable LSD sort)
 
 #include "pqps_hip.h"
@@ -114,29 +116,33 @@ __global__ void synth_kernel(uint64_t seed, uint64_t row0, uint64_t n,
         synth_store(c, i, synth_row(seed, row0 + i, cdf, shell));
 }
 
-// ---- all-gatherv tail: padded per-rank segments -> one contiguous ID list -------
-// segs[r * seg_cap .. + counts[r]) are rank r's ascending IDs (what an equal-size
-// all-gather delivered); merged = their rank-order concatenation, the layout
-// MPI_Allgatherv produces from recvCounts/displs (engine/mpi/executeEngine-mpi.c:758-765).
-__global__ __launch_bounds__(256) void merge_segments_kernel(const uint32_t *segs, const uint64_t *counts,
-                                                             uint32_t world, uint64_t seg_cap,
-                                                             uint32_t *merged, uint64_t merged_cap, uint64_t *total_out) {
+// ---- all-gatherv tail: per-rank slots -> one contiguous ID list ------------------------------
+// A slot = [u64 match count][u64 reserved][u32 IDs ...] exactly as one rank's filter left it
+// (pqps_filter_scan wrote the count and the IDs into it), `slot_stride` u32 apart -- what ONE
+// equal-size all-gather delivers.  merged = rank-order concatenation of the ID lists, the layout
+// MPI_Allgatherv produces from recvCounts / displs (engine/mpi/executeEngine-mpi.c:753-765).
+constexpr uint32_t kSlotHeaderWords = 4;         // u32 words in front of the IDs
+
+__global__ __launch_bounds__(256) void merge_slots_kernel(const uint32_t *slots, uint32_t world, uint64_t slot_stride,
+                                                          uint32_t *merged, uint64_t merged_cap, uint64_t *total_out) {
     const uint32_t r = blockIdx.y;
-    uint64_t displ = 0, total = 0;
+    const uint64_t seg_cap = slot_stride - kSlotHeaderWords;
+    uint64_t displ = 0, total = 0, raw = 0;
     for (uint32_t i = 0; i < world; i++) {
-        const uint64_t c = counts[i] < seg_cap ? counts[i] : seg_cap;
+        const uint64_t reported = *(const uint64_t *)(slots + (uint64_t)i * slot_stride);
+        const uint64_t c = reported < seg_cap ? reported : seg_cap;
         if (i < r) displ += c;
         total += c;
+        raw += reported;
     }
-    const uint64_t cnt = counts[r] < seg_cap ? counts[r] : seg_cap;
-    const uint32_t *src = segs + (uint64_t)r * seg_cap;
+    const uint64_t mine = *(const uint64_t *)(slots + (uint64_t)r * slot_stride);
+    const uint64_t cnt = mine < seg_cap ? mine : seg_cap;
+    const uint32_t *src = slots + (uint64_t)r * slot_stride + kSlotHeaderWords;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
         if (displ + i < merged_cap) merged[displ + i] = src[i];
     if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) {
-        uint64_t raw = 0;
-        for (uint32_t i = 0; i < world; i++) raw += counts[i];
         total_out[0] = total;          // IDs actually merged
-        total_out[1] = raw;            // IDs the ranks reported (> total means a segment overflowed)
+        total_out[1] = raw;            // IDs the ranks reported (> total means a slot overflowed)
     }
 }
 
@@ -352,7 +358,11 @@ uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps) {
 
 // K1 (+ K2 + K3 for ID output).  `rows` = scan rows or the gather upper bound.
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
-               uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s) {
+               uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
+               hipEvent_t done = nullptr) {
+    // `done` (optional) becomes ready when the last kernel of this query has finished.  It rides on
+    // that kernel's own dispatch packet: a separate hipEventRecord would put a barrier packet behind
+    // it and cost the NEXT query on this stream ~7 us of idle queue.
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
@@ -364,12 +374,17 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.n_super = (uint32_t)((groups + kSuperGroups - 1) / kSuperGroups);
     const uint32_t grid = eval_grid(ctx, steps);
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
-    if (timed) HIP_TRY(hipEventRecord(ctx->ev_start[ctx->timed], s));
-    hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
+    if (timed) {
+        // the two events are attached to the dispatch itself: they carry the kernel's own begin /
+        // end timestamps (what rocprofv3 --kernel-trace reports), not the queueing around it
+        hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, ctx->ev_start[ctx->timed], ctx->ev_eval[ctx->timed], 0, a);
+    } else {
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
+    }
     HIP_TRY(hipGetLastError());
-    if (timed) HIP_TRY(hipEventRecord(ctx->ev_eval[ctx->timed], s));
     if (mode != MODE_IDS) {
-        hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, out_count);
+        if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, grid, out_count);
+        else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, out_count);
         HIP_TRY(hipGetLastError());
     } else {
         SumArgs sa;
@@ -387,11 +402,14 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         ea.cand = a.cand; ea.range = a.range; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
         if (groups) {
             const uint64_t cap = (uint64_t)ctx->compute_units * 32;
-            hipLaunchKernelGGL(expand_kernel, dim3((uint32_t)(groups < cap ? groups : cap)), dim3(kBlock), 0, s, ea);
+            const dim3 eg((uint32_t)(groups < cap ? groups : cap));
+            if (done) hipExtLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, nullptr, done, 0, ea);
+            else hipLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, ea);
             HIP_TRY(hipGetLastError());
         } else {
             // no rows at all: the count is the base (0, or unchanged when appending)
             if (!gather) HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
+            if (done) HIP_TRY(hipEventRecord(done, s));
         }
     }
     if (timed) { HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
@@ -757,18 +775,193 @@ int pqps_bump_codes(pqps_ctx *ctx, void *codes, uint32_t width, uint64_t n_rows,
     return PQPS_OK;
 }
 
-int pqps_merge_segments(pqps_ctx *ctx, const uint32_t *segments, const uint64_t *counts, uint32_t world,
-                        uint64_t segment_capacity, uint32_t *merged, uint64_t merged_capacity,
-                        uint64_t *totals, void *stream) {
-    if (!ctx || !segments || !counts || !merged) return fail(PQPS_EINVAL, "NULL argument");
+int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint64_t slot_stride,
+                     uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream) {
+    if (!ctx || !slots || !merged) return fail(PQPS_EINVAL, "NULL argument");
     if (world == 0 || world > 1024) return fail(PQPS_EINVAL, "world %u out of range", world);
+    if (slot_stride <= kSlotHeaderWords || (slot_stride & 1u)) return fail(PQPS_EINVAL, "slot stride %llu too small or odd", (unsigned long long)slot_stride);
+    if (((uintptr_t)slots & 7u) != 0) return fail(PQPS_EINVAL, "slots must be 8-byte aligned");
     hipStream_t s = pick_stream(ctx, stream);
-    uint64_t bx = (segment_capacity + 255) / 256;
+    uint64_t bx = (slot_stride + 255) / 256;
     if (bx > 1024) bx = 1024;
-    if (bx == 0) bx = 1;
-    hipLaunchKernelGGL(merge_segments_kernel, dim3((uint32_t)bx, world), dim3(256), 0, s,
-                       segments, counts, world, segment_capacity, merged, merged_capacity, totals);
+    hipLaunchKernelGGL(merge_slots_kernel, dim3((uint32_t)bx, world), dim3(256), 0, s,
+                       slots, world, slot_stride, merged, merged_capacity, totals);
     HIP_TRY(hipGetLastError());
+    return PQPS_OK;
+}
+
+// ---- multi-GPU SELECT: shard scan + one RCCL all-gather + device merge -------------------------
+// The whole exchange step of engine/mpi/executeEngine-mpi.c:703-768 behind ONE host call per query:
+// scan kernels on the caller's stream, then -- on the exchange's own stream, behind an event -- the
+// all-gather of this rank's [count | IDs] slot and the compaction.  RCCL is resolved at run time from
+// the library the caller names (the process's torch build ships one; /opt/rocm/lib/librccl.so is the
+// system one), so the single-GPU engine does not link against it.
+}  // extern "C"
+
+namespace {
+
+struct RcclApi {
+    void *dl;
+    int (*GetUniqueId)(void *id);
+    int (*CommInitRank)(void **comm, int nranks, pqps_rccl_id id, int rank);
+    int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s);
+    int (*CommDestroy)(void *comm);
+    const char *(*GetErrorString)(int rc);
+};
+
+constexpr int kRcclInt32 = 2;      // ncclInt32 (rccl.h: ncclDataType_t)
+
+int load_rccl(const char *path, RcclApi *api) {
+    if (!path || !*path) return fail(PQPS_EINVAL, "RCCL library path is empty");
+    api->dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!api->dl) return fail(PQPS_EHIP, "dlopen(%s): %s", path, dlerror());
+    struct { const char *name; void **slot; } syms[] = {
+        {"ncclGetUniqueId", (void **)&api->GetUniqueId},   {"ncclCommInitRank", (void **)&api->CommInitRank},
+        {"ncclAllGather", (void **)&api->AllGather},       {"ncclCommDestroy", (void **)&api->CommDestroy},
+        {"ncclGetErrorString", (void **)&api->GetErrorString},
+    };
+    for (auto &sy : syms) {
+        *sy.slot = dlsym(api->dl, sy.name);
+        if (!*sy.slot) return fail(PQPS_EHIP, "%s: symbol %s not found", path, sy.name);
+    }
+    return PQPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct pqps_exchange {
+    pqps_ctx *ctx;
+    RcclApi rccl;
+    void *comm;
+    uint32_t world, rank, ring;
+    uint64_t cap, stride;            // IDs per slot; u32 words per slot (header + IDs)
+    hipStream_t stream;              // the exchange stream
+    uint32_t *local;                 // [ring][stride]          this rank's slots
+    uint32_t *slots;                 // [ring][world][stride]   gathered
+    uint32_t *merged;                // [ring][world * cap]
+    uint64_t *totals;                // [ring][2]
+    hipEvent_t *scan_done, *merge_done;
+    bool *used;
+};
+
+int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id) {
+    if (!id) return fail(PQPS_EINVAL, "id is NULL");
+    RcclApi api{};
+    int rc = load_rccl(rccl_library, &api);
+    if (rc) return rc;
+    int nrc = api.GetUniqueId(id);
+    if (nrc) return fail(PQPS_EHIP, "ncclGetUniqueId: %s", api.GetErrorString(nrc));
+    return PQPS_OK;
+}
+
+int pqps_exchange_destroy(pqps_exchange *x) {
+    if (!x) return PQPS_OK;
+    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->comm) (void)x->rccl.CommDestroy(x->comm);
+    for (uint32_t i = 0; i < x->ring; i++) {
+        if (x->scan_done) (void)hipEventDestroy(x->scan_done[i]);
+        if (x->merge_done) (void)hipEventDestroy(x->merge_done[i]);
+    }
+    delete[] x->scan_done; delete[] x->merge_done; delete[] x->used;
+    if (x->local) (void)hipFree(x->local);
+    if (x->slots) (void)hipFree(x->slots);
+    if (x->merged) (void)hipFree(x->merged);
+    if (x->totals) (void)hipFree(x->totals);
+    if (x->stream) (void)hipStreamDestroy(x->stream);
+    delete x;
+    return PQPS_OK;
+}
+
+int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world, uint32_t rank,
+                         uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
+    if (!ctx || !id || !out) return fail(PQPS_EINVAL, "NULL argument");
+    if (world == 0 || world > 1024 || rank >= world) return fail(PQPS_EINVAL, "rank %u / world %u out of range", rank, world);
+    if (ring == 0 || ring > 64) return fail(PQPS_EINVAL, "ring %u out of range (1..64)", ring);
+    if (slot_capacity == 0 || slot_capacity > 0xFFFFFFFFull) return fail(PQPS_EINVAL, "slot capacity out of range");
+    pqps_exchange *x = new (std::nothrow) pqps_exchange();
+    if (!x) return fail(PQPS_ENOMEM, "out of host memory");
+    x->ctx = ctx; x->world = world; x->rank = rank; x->ring = ring;
+    x->cap = (slot_capacity + 1) & ~1ull;                      // keeps every slot 8-byte aligned
+    x->stride = x->cap + kSlotHeaderWords;
+    int rc = load_rccl(rccl_library, &x->rccl);
+    if (rc) { pqps_exchange_destroy(x); return rc; }
+#define X_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { pqps_exchange_destroy(x); \
+        return fail(PQPS_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    X_TRY(hipSetDevice(ctx->device));
+    X_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
+    X_TRY(hipMalloc((void **)&x->local, (size_t)ring * x->stride * 4));
+    X_TRY(hipMalloc((void **)&x->slots, (size_t)ring * world * x->stride * 4));
+    X_TRY(hipMalloc((void **)&x->merged, (size_t)ring * world * x->cap * 4));
+    X_TRY(hipMalloc((void **)&x->totals, (size_t)ring * 2 * sizeof(uint64_t)));
+    X_TRY(hipMemset(x->local, 0, (size_t)ring * x->stride * 4));
+    X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
+    x->scan_done = new hipEvent_t[ring](); x->merge_done = new hipEvent_t[ring](); x->used = new bool[ring]();
+    for (uint32_t i = 0; i < ring; i++) {
+        X_TRY(hipEventCreateWithFlags(&x->scan_done[i], hipEventDisableTiming));
+        X_TRY(hipEventCreateWithFlags(&x->merge_done[i], hipEventDisableTiming));
+    }
+#undef X_TRY
+    int nrc = x->rccl.CommInitRank(&x->comm, (int)world, *id, (int)rank);
+    if (nrc) {
+        x->comm = nullptr;
+        rc = fail(PQPS_EHIP, "ncclCommInitRank(world %u, rank %u): %s", world, rank, x->rccl.GetErrorString(nrc));
+        pqps_exchange_destroy(x);
+        return rc;
+    }
+    *out = x;
+    return PQPS_OK;
+}
+
+int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                         const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
+    if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
+    // the slot is free again once the merge that last used it has finished (a host wait, normally
+    // long satisfied: the scan stream carries no cross-stream barrier)
+    if (x->used[slot]) HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    uint32_t *local = x->local + (uint64_t)slot * x->stride;
+    uint32_t *slots = x->slots + (uint64_t)slot * x->world * x->stride;
+    hipStream_t scan = pick_stream(x->ctx, scan_stream);
+    if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
+        return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
+    int rc = check_pred(cols, n_cols, pred);
+    if (rc) return rc;
+    EvalArgs a;
+    fill_args(a, cols, n_cols, pred);
+    a.n_rows = n_rows;
+    rc = run_filter(x->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
+                    local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan, x->scan_done[slot]);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    int nrc = x->rccl.AllGather(local, slots, (size_t)x->stride, kRcclInt32, x->comm, x->stream);   // mpi:753 + mpi:765
+    if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+    rc = pqps_merge_slots(x->ctx, slots, x->world, x->stride, x->merged + (uint64_t)slot * x->world * x->cap,
+                          x->world * x->cap, x->totals + 2 * (uint64_t)slot, (void *)x->stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
+    x->used[slot] = true;
+    return PQPS_OK;
+}
+
+int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
+                         uint64_t totals[2]) {
+    if (!x || !totals) return fail(PQPS_EINVAL, "NULL argument");
+    if (slot >= x->ring || !x->used[slot]) return fail(PQPS_EINVAL, "slot %u holds no result", slot);
+    HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    HIP_TRY(hipMemcpy(totals, x->totals + 2 * (uint64_t)slot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (local_count) HIP_TRY(hipMemcpy(local_count, x->local + (uint64_t)slot * x->stride, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (merged_dev) *merged_dev = x->merged + (uint64_t)slot * x->world * x->cap;
+    if (totals[1] > totals[0])
+        return fail(PQPS_EOVERFLOW, "exchange slot overflow: %llu IDs reported, capacity %llu per rank",
+                    (unsigned long long)totals[1], (unsigned long long)x->cap);
+    return PQPS_OK;
+}
+
+int pqps_exchange_sync(pqps_exchange *x) {
+    if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    HIP_TRY(hipStreamSynchronize(x->stream));
     return PQPS_OK;
 }
 

@@ -5,10 +5,10 @@ exchange mirrors the only row-range data-parallel path of the reference,
 executeQueryDeleteMPI (engine/mpi/executeEngine-mpi.c):
 
     :703-715  block partition of the rows           -> shard_rows()
-    :753      MPI_Allgather of the per-rank sizes   -> all_gather of match counts
+    :753      MPI_Allgather of the per-rank sizes   -> the count rides in the slot header
     :758-762  displacements = exclusive prefix      -> done on the device
-    :765      MPI_Allgatherv of the payload         -> equal-size all_gather of
-              ID slots + pqps_merge_segments (device) / torch indexing (CPU)
+    :765      MPI_Allgatherv of the payload         -> ONE equal-size all_gather of
+              [count | IDs] slots + pqps_merge_slots (device) / torch indexing (CPU)
 
 Rank-order concatenation of ascending per-shard lists IS the ascending global
 list, so scan-mode results stay bit-exact with the single-GPU / QPESeq answer.
@@ -29,59 +29,83 @@ def shard_rows(n_rows: int, world: int, rank: int):
     return rem * (base + 1) + (rank - rem) * base, base
 
 
+SLOT_HEADER_WORDS = 4     # include/pqps_hip.h: [u64 count][u64 reserved] in front of the IDs
+
+
 class IdMerger:
-    """Buffers + the three-step merge for one (world, slot capacity).
+    """Buffers + the merge for one (world, slot capacity).
 
-    ids_local / count_local are written by pqps_filter_scan; after merge(),
-    `merged[:totals[0]]` on EVERY rank holds the global ascending ID list."""
+    The filter writes its count to `count_ptr` and its IDs to `ids_ptr` -- both inside this
+    rank's slot -- so ONE equal-size all-gather moves count and payload together; after
+    merge(), `merged[:totals[0]]` on EVERY rank holds the global ascending ID list."""
 
-    def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False):
+    def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False,
+                 always_collective=False):
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
-        # host_staged: collectives run on CPU copies (gloo rehearsal of the GPU control flow on a
+        # host_staged: the collective runs on CPU copies (gloo rehearsal of the GPU control flow on a
         # box where RCCL cannot be used, e.g. several ranks sharing one device); never the fast path
         self.host_staged = host_staged
+        self.always_collective = always_collective      # world == 1 still goes through the collective (rehearsal)
         self.cap = int(slot_capacity)
+        self.stride = self.cap + SLOT_HEADER_WORDS            # u32 words per slot (even)
+        if self.stride % 2:
+            self.cap += 1
+            self.stride += 1
         self.device = device
         self.ctx, self.pq = ctx, pq
         t = torch
-        self.ids_local = t.zeros(self.cap, dtype=t.int32, device=device)       # u32 payload, int32 container
-        self.count_local = t.zeros(1, dtype=t.int64, device=device)
-        self.counts = t.zeros(world, dtype=t.int64, device=device)
-        self.slots = t.zeros(world * self.cap, dtype=t.int32, device=device)
+        self.slot_local = t.zeros(self.stride, dtype=t.int32, device=device)     # u32 payload, int32 container
+        self.slots = t.zeros(world * self.stride, dtype=t.int32, device=device)
         self.merged = t.zeros(world * self.cap, dtype=t.int32, device=device)
         self.totals = t.zeros(2, dtype=t.int64, device=device)
 
+    @property
+    def count_ptr(self):
+        return self.slot_local.data_ptr()
+
+    @property
+    def ids_ptr(self):
+        return self.slot_local.data_ptr() + 4 * SLOT_HEADER_WORDS
+
+    def set_local(self, ids_u32, count=None):
+        """Fills this rank's slot from a numpy uint32 array (CPU tests)."""
+        import numpy as np
+        k = min(len(ids_u32), self.cap)
+        self.slot_local[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + k] = self.torch.from_numpy(ids_u32[:k].view(np.int32).copy())
+        c = len(ids_u32) if count is None else count
+        self.slot_local[0:2] = self.torch.from_numpy(np.array([c], dtype=np.uint64).view(np.int32).copy())
+
+    def local_count(self):
+        return int(self.slot_local[0:2].cpu().numpy().view("uint64")[0])
+
     def merge(self, stream_ptr=None):
-        """Collectives + compaction, all enqueued on the current torch stream."""
+        """One collective + compaction, enqueued on the current torch stream."""
         dist, t = self.dist, self.torch
-        if self.world == 1:
-            self.counts.copy_(self.count_local)
-            self.slots.copy_(self.ids_local)
+        if self.world == 1 and not self.always_collective:
+            self.slots.copy_(self.slot_local)
         elif self.host_staged:
-            c_loc, i_loc = self.count_local.cpu(), self.ids_local.cpu()
-            c_all = [t.zeros_like(c_loc) for _ in range(self.world)]
-            i_all = [t.zeros_like(i_loc) for _ in range(self.world)]
-            dist.all_gather(c_all, c_loc)
-            dist.all_gather(i_all, i_loc)
-            self.counts.copy_(t.cat(c_all))
-            self.slots.copy_(t.cat(i_all))
+            loc = self.slot_local.cpu()
+            parts = [t.zeros_like(loc) for _ in range(self.world)]
+            dist.all_gather(parts, loc)
+            self.slots.copy_(t.cat(parts))
         else:
-            dist.all_gather_into_tensor(self.counts, self.count_local)           # mpi:753
-            dist.all_gather_into_tensor(self.slots, self.ids_local)              # mpi:765 (equal-size slots)
+            dist.all_gather_into_tensor(self.slots, self.slot_local)       # mpi:753 + mpi:765 in one collective
         if self.device.type == "cuda":
-            self.pq.check(self.pq.lib().pqps_merge_segments(
-                self.ctx.h, self.slots.data_ptr(), self.counts.data_ptr(), self.world, self.cap,
-                self.merged.data_ptr(), self.merged.numel(), self.totals.data_ptr(), stream_ptr), "pqps_merge_segments")
+            self.pq.check(self.pq.lib().pqps_merge_slots(
+                self.ctx.h, self.slots.data_ptr(), self.world, self.stride,
+                self.merged.data_ptr(), self.merged.numel(), self.totals.data_ptr(), stream_ptr), "pqps_merge_slots")
         else:
-            # CPU tensors (gloo rehearsal / unit tests): same layout arithmetic in torch
-            counts = t.clamp(self.counts, max=self.cap)
-            displ = 0
+            # CPU tensors (gloo unit tests): same layout arithmetic in torch
+            displ = raw = 0
             for r in range(self.world):
-                c = int(counts[r])
-                self.merged[displ:displ + c] = self.slots[r * self.cap:r * self.cap + c]
+                slot = self.slots[r * self.stride:(r + 1) * self.stride]
+                reported = int(slot[0:2].numpy().view("uint64")[0])
+                c = min(reported, self.cap)
+                self.merged[displ:displ + c] = slot[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + c]
                 displ += c
+                raw += reported
             self.totals[0] = displ
-            self.totals[1] = int(self.counts.sum())
+            self.totals[1] = raw
 
     def result(self):
         """Host copy of the merged IDs as uint32 numpy (synchronises)."""
@@ -89,3 +113,60 @@ class IdMerger:
         if int(tot[1]) > int(tot[0]):
             raise RuntimeError(f"merge slot overflow: {int(tot[1])} IDs reported, capacity {self.cap} per rank")
         return self.merged[:int(tot[0])].cpu().numpy().view("uint32")
+
+
+def default_rccl_library(torch=None):
+    """The RCCL that goes with the HIP runtime this process runs on: under torch (which loads its
+    own bundled libamdhip64 + librccl) the bundled one, otherwise the system one."""
+    import os
+    if torch is not None:
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    return "/opt/rocm/lib/librccl.so"
+
+
+class ShardExchange:
+    """Native exchange (include/pqps_hip.h: pqps_exchange_*): ONE host call per query enqueues the
+    shard scan, the RCCL all-gather of the [count | IDs] slot and the device merge (mpi:717-768).
+
+    torch.distributed is only the bootstrap: rank 0's RCCL id reaches the other ranks through
+    broadcast_object_list; the data path is ncclAllGather called from the shim on its own stream."""
+
+    def __init__(self, pq, ctx, torch, dist, world, rank, slot_capacity, ring=4, rccl_library=None):
+        import ctypes as C
+        self.pq, self.ctx, self.world, self.rank, self.ring = pq, ctx, world, rank, ring
+        L = pq.lib()
+        path = (rccl_library or default_rccl_library(torch)).encode()
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            pq.check(L.pqps_exchange_unique_id(path, ident), "pqps_exchange_unique_id")
+        box = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        pq.check(L.pqps_exchange_create(ctx.h, path, ident, world, rank, int(slot_capacity), ring, C.byref(h)),
+                 "pqps_exchange_create")
+        self.h = h
+
+    def select(self, cols, n_cols, n_rows, id_base, pred_ref, slot, stream_ptr):
+        self.pq.check(self.pq.lib().pqps_exchange_select(self.h, cols, n_cols, n_rows, id_base, pred_ref, slot, stream_ptr),
+                      "pqps_exchange_select")
+
+    def result(self, slot):
+        """(merged uint32 numpy array, this rank's own match count); waits for the slot's merge."""
+        import ctypes as C
+        import numpy as np
+        ptr, local, totals = C.c_void_p(), C.c_uint64(), (C.c_uint64 * 2)()
+        self.pq.check(self.pq.lib().pqps_exchange_result(self.h, slot, C.byref(ptr), C.byref(local), totals),
+                      "pqps_exchange_result")
+        out = np.empty(int(totals[0]), dtype=np.uint32)
+        if len(out):
+            self.ctx.download(out.ctypes.data, ptr.value, out.nbytes)
+        return out, int(local.value)
+
+    def close(self):
+        if self.h:
+            self.pq.check(self.pq.lib().pqps_exchange_destroy(self.h), "pqps_exchange_destroy")
+            self.h = None

@@ -12,6 +12,7 @@
     against the host twin, shard concatenation == whole-table result.
 """
 import ctypes as C
+import os
 import hashlib
 import json
 import random
@@ -143,6 +144,117 @@ def test_id_base_and_shard_concatenation(ctx):
         out.free()
         dev.free()
     assert np.array_equal(np.concatenate(parts), whole)
+
+def test_merge_slots_is_the_allgatherv_layout(ctx):
+    """8 shards filtered straight into [count | IDs] slots (what pqps_exchange_select / merge.py hand to
+    the all-gather), laid out rank after rank as the collective delivers them, compacted on the device
+    by pqps_merge_slots: equals the whole-table answer; a slot that overflowed is reported."""
+    n, world, hdr = 1_000_003, 8, pq.SLOT_HEADER_WORDS
+    chain = QUERIES["Q_B"]
+    whole = q.HostSynth(n, seed=5).oracle_scan(chain)
+    shard_max = 0
+    bounds = []
+    for r in range(world):
+        s_, c_ = C.c_uint64(), C.c_uint64()
+        pq.lib().pqps_partition(n, world, r, C.byref(s_), C.byref(c_))
+        bounds.append((s_.value, c_.value))
+    for cap, expect_overflow in ((len(whole) // world * 2 + 64) & ~1, False), (1000, True):
+        stride = cap + hdr
+        slots = ctx.malloc(world * stride * 4)
+        ctx.memset(slots, 0, world * stride * 4)
+        merged = ctx.malloc(world * cap * 4)
+        totals = ctx.malloc(16)
+        for r, (start, count) in enumerate(bounds):
+            dev = pq.SyntheticTable(ctx, count, seed=5, row0=start)
+            pred, cols, nc, _ = dev.bind(chain)
+            base = slots + r * stride * 4
+            rc = pq.lib().pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), base + 4 * hdr, cap, base, None)
+            pq.check(rc, "pqps_filter_scan")
+            ctx.sync()
+            dev.free()
+        pq.check(pq.lib().pqps_merge_slots(ctx.h, slots, world, stride, merged, world * cap, totals, None), "pqps_merge_slots")
+        ctx.sync()
+        t = (C.c_uint64 * 2)()
+        ctx.download(t, totals, 16)
+        assert t[1] == len(whole)
+        if expect_overflow:
+            assert t[0] == world * cap < t[1]
+        else:
+            assert t[0] == len(whole)
+            got = np.zeros(len(whole), dtype=np.uint32)
+            ctx.download(got.ctypes.data, merged, got.nbytes)
+            assert np.array_equal(got, whole)
+        for p_ in (slots, merged, totals):
+            ctx.free(p_)
+    # argument validation
+    assert pq.lib().pqps_merge_slots(ctx.h, None, world, 100, None, 0, None, None) == -1
+    assert pq.lib().pqps_merge_slots(ctx.h, 8, 0, 100, 8, 0, None, None) == -1
+    assert pq.lib().pqps_merge_slots(ctx.h, 8, 2, 4, 8, 0, None, None) == -1       # stride leaves no room for IDs
+
+
+def test_native_exchange_world_of_one(ctx):
+    """pqps_exchange_*: scan + ncclAllGather + merge behind one call.  One GPU here, so a world of 1:
+    checks the RCCL plumbing (dlopen, communicator, the collective on the exchange stream), slot
+    reuse round the ring, and that every query's merged list equals the oracle's."""
+    import importlib.util
+    torch = None        # no torch in this process: the shim's HIP runtime is the system one, and so is the RCCL it loads
+    spec = importlib.util.spec_from_file_location("pqps_merge", q.PKG / "merge.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    n = 300_007
+    host = q.HostSynth(n, seed=9)
+    dev = pq.SyntheticTable(ctx, n, seed=9)
+    names = ["Q_B", "S1", "none", "Q_A", "S7", "Q_B", "neq"]
+    want = {k: host.oracle_scan(QUERIES[k]) for k in set(names)}
+    xch = mg.ShardExchange(pq, ctx, torch, None, 1, 0, n, ring=2)
+    try:
+        pending = []
+        for i, name in enumerate(names):
+            pred, cols, nc, _ = dev.bind(QUERIES[name])
+            slot = i % 2
+            if len(pending) == 2:                          # read a slot's result before the ring reuses it
+                j, nm = pending.pop(0)
+                got, local = xch.result(j)
+                assert local == len(want[nm]) and np.array_equal(got, want[nm]), nm
+            xch.select(cols, nc, n, 0, C.byref(pred), slot, None)
+            pending.append((slot, name))
+        for j, nm in pending:
+            got, local = xch.result(j)
+            assert local == len(want[nm]) and np.array_equal(got, want[nm]), nm
+    finally:
+        xch.close()
+        dev.free()
+    # overflow: a slot smaller than the answer is reported, not silently truncated
+    dev = pq.SyntheticTable(ctx, n, seed=9)
+    xch = mg.ShardExchange(pq, ctx, torch, None, 1, 0, 1000, ring=1)
+    try:
+        pred, cols, nc, _ = dev.bind(QUERIES["neq"])
+        xch.select(cols, nc, n, 0, C.byref(pred), 0, None)
+        with pytest.raises(pq.PqpsError):
+            xch.result(0)
+    finally:
+        xch.close()
+        dev.free()
+
+
+def test_bench_exchange_path_runs_on_one_gpu():
+    """bench.py --force-merge: the N > 1 code path (torch.distributed bootstrap over RCCL, shim-driven
+    all-gather + merge on the exchange stream, ring of slots) with a world of 1, in its own process
+    with bench.py's load order.  stdout must be exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    for mode in ("rccl", "torch"):
+        p = subprocess.run([sys.executable, str(q.ROOT / "bench.py"), "--rows", "3000000", "--steps", "9", "--warmup", "2",
+                            "--no-extras", "--no-cpu-baseline", "--force-merge", "--exchange", mode],
+                           capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout[:2000]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["steps"] == 9 and d["config"]["matches_total"] > 0
+        assert ("shim-driven" if mode == "rccl" else "torch.distributed") in d["config"]["parallelism"]
 
 
 def test_flags_mode(ctx):

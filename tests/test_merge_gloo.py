@@ -1,5 +1,5 @@
-"""The N > 1 path on CPU: row-range sharding (mpi:703-715) + count all-gather + slot
-all-gather + rank-order compaction (merge.py), world_size 2 and 3 over gloo.
+"""The N > 1 path on CPU: row-range sharding (mpi:703-715) + [count | IDs] slot all-gather
++ rank-order compaction (merge.py), world_size 2 and 3 over gloo.
 
 Each rank filters ITS shard with the oracle (the checker stands in for the GPU filter,
 which needs a device), the shards' ascending ID lists are merged on every rank, and
@@ -38,9 +38,7 @@ WORKER = textwrap.dedent("""
         host = q.HostSynth(count, seed=11, row0=start)
         local = host.oracle_scan(q.chain_from_jsonable(chain), id_base=start)
         m = mg.IdMerger(torch, dist, world, rank, cap, torch.device("cpu"))
-        k = min(len(local), cap)
-        m.ids_local[:k] = torch.from_numpy(local[:k].view(np.int32).copy())
-        m.count_local[0] = len(local)
+        m.set_local(local)
         m.merge()
         try:
             out[name] = m.result().tolist()
