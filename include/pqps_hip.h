@@ -198,6 +198,11 @@ int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rcc
                          uint32_t rank, uint64_t slot_capacity, uint32_t ring, pqps_exchange **out);
 int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                          uint32_t id_base, const pqps_predicate *pred, uint32_t slot, void *scan_stream);
+/* COUNT(*) across the shards: local count kernel + ncclAllReduce(sum, 1 x u64)
+ * (engine/mpi/executeEngine-mpi.c:745).  pqps_exchange_result() then reports totals[0] = the global
+ * count, *local_count = this rank's; the merged pointer is meaningless for such a slot. */
+int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                        const pqps_predicate *pred, uint32_t slot, void *scan_stream);
 int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
                          uint64_t totals[2]);
 int pqps_exchange_sync(pqps_exchange *x);

@@ -239,6 +239,7 @@ def lib():
     L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
     L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]
     L.pqps_exchange_select.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), u32, vp]
+    L.pqps_exchange_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), u32, vp]
     L.pqps_exchange_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.pqps_exchange_sync.argtypes = [vp]
     L.pqps_exchange_destroy.argtypes = [vp]

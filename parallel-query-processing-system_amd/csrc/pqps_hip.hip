@@ -805,11 +805,14 @@ struct RcclApi {
     int (*GetUniqueId)(void *id);
     int (*CommInitRank)(void **comm, int nranks, pqps_rccl_id id, int rank);
     int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s);
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s);
     int (*CommDestroy)(void *comm);
     const char *(*GetErrorString)(int rc);
 };
 
 constexpr int kRcclInt32 = 2;      // ncclInt32 (rccl.h: ncclDataType_t)
+constexpr int kRcclUint64 = 5;     // ncclUint64
+constexpr int kRcclSum = 0;        // ncclSum (ncclRedOp_t)
 
 int load_rccl(const char *path, RcclApi *api) {
     if (!path || !*path) return fail(PQPS_EINVAL, "RCCL library path is empty");
@@ -818,6 +821,7 @@ int load_rccl(const char *path, RcclApi *api) {
     struct { const char *name; void **slot; } syms[] = {
         {"ncclGetUniqueId", (void **)&api->GetUniqueId},   {"ncclCommInitRank", (void **)&api->CommInitRank},
         {"ncclAllGather", (void **)&api->AllGather},       {"ncclCommDestroy", (void **)&api->CommDestroy},
+        {"ncclAllReduce", (void **)&api->AllReduce},
         {"ncclGetErrorString", (void **)&api->GetErrorString},
     };
     for (auto &sy : syms) {
@@ -940,6 +944,31 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     rc = pqps_merge_slots(x->ctx, slots, x->world, x->stride, x->merged + (uint64_t)slot * x->world * x->cap,
                           x->world * x->cap, x->totals + 2 * (uint64_t)slot, (void *)x->stream);
     if (rc) return rc;
+    HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
+    x->used[slot] = true;
+    return PQPS_OK;
+}
+
+int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                        const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
+    if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
+    if (x->used[slot]) HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    uint32_t *local = x->local + (uint64_t)slot * x->stride;
+    uint64_t *totals = x->totals + 2 * (uint64_t)slot;
+    hipStream_t scan = pick_stream(x->ctx, scan_stream);
+    int rc = check_pred(cols, n_cols, pred);
+    if (rc) return rc;
+    EvalArgs a;
+    fill_args(a, cols, n_cols, pred);
+    a.n_rows = n_rows;
+    rc = run_filter(x->ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false, 0,
+                    nullptr, 0, (uint64_t *)local, scan, x->scan_done[slot]);
+    if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), x->stream));
+    int nrc = x->rccl.AllReduce(local, totals, 1, kRcclUint64, kRcclSum, x->comm, x->stream);      // mpi:745
+    if (nrc) return fail(PQPS_EHIP, "ncclAllReduce: %s", x->rccl.GetErrorString(nrc));
     HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
     x->used[slot] = true;
     return PQPS_OK;

@@ -154,6 +154,18 @@ class ShardExchange:
         self.pq.check(self.pq.lib().pqps_exchange_select(self.h, cols, n_cols, n_rows, id_base, pred_ref, slot, stream_ptr),
                       "pqps_exchange_select")
 
+    def count(self, cols, n_cols, n_rows, pred_ref, slot, stream_ptr):
+        """COUNT(*): local count kernel + all-reduce (mpi:745); read it back with count_result()."""
+        self.pq.check(self.pq.lib().pqps_exchange_count(self.h, cols, n_cols, n_rows, pred_ref, slot, stream_ptr),
+                      "pqps_exchange_count")
+
+    def count_result(self, slot):
+        """(global count, this rank's count) of a count() slot."""
+        import ctypes as C
+        local, totals = C.c_uint64(), (C.c_uint64 * 2)()
+        self.pq.check(self.pq.lib().pqps_exchange_result(self.h, slot, None, C.byref(local), totals), "pqps_exchange_result")
+        return int(totals[0]), int(local.value)
+
     def result(self, slot):
         """(merged uint32 numpy array, this rank's own match count); waits for the slot's merge."""
         import ctypes as C

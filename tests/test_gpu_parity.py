@@ -221,6 +221,14 @@ def test_native_exchange_world_of_one(ctx):
         for j, nm in pending:
             got, local = xch.result(j)
             assert local == len(want[nm]) and np.array_equal(got, want[nm]), nm
+        # COUNT(*) = count kernel + all-reduce (mpi:745), interleaved with an ID query on the other slot
+        for nm in ("Q_B", "none", "seven_leaves"):
+            pred, cols, nc, _ = dev.bind(QUERIES[nm])
+            xch.count(cols, nc, n, C.byref(pred), 0, None)
+            pred2, cols2, nc2, _ = dev.bind(QUERIES["S1"])
+            xch.select(cols2, nc2, n, 0, C.byref(pred2), 1, None)
+            assert xch.count_result(0) == (len(host.oracle_scan(QUERIES[nm])),) * 2, nm
+            assert np.array_equal(xch.result(1)[0], want["S1"])
     finally:
         xch.close()
         dev.free()
