@@ -77,6 +77,9 @@ bool buildDeviceTableHIP(struct engineS *engine);
 void rebuildDeviceTableHIP(struct engineS *engine);
 /* INSERT: appends engine->all_records[num_records-1] to the device table in place. */
 void appendRowDeviceTableHIP(struct engineS *engine);
+/* DELETE: `delete_flags_dev` (1 = row goes, from pqps_filter_flags) compacts the device columns
+ * in place; `expected_rows` = survivors counted on the host (cross-check). */
+void compactDeviceTableHIP(struct engineS *engine, const uint8_t *delete_flags_dev, size_t expected_rows);
 void destroyDeviceTableHIP(struct engineS *engine);
 
 /* Lower-level pieces (also used for ad-hoc tables over caller-supplied rows,

@@ -163,6 +163,13 @@ int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int
                      uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
                      uint64_t *range, void *stream);
 
+/* DELETE on the device (engine/serial/executeEngine-serial.c:645-676 removes the matching rows and
+ * keeps the survivors in order): `delete_flags` is what pqps_filter_flags produced (1 = row goes).
+ * Every column is compacted in place to the surviving rows, order preserved; *kept_out = survivors.
+ * Synchronises the stream.  Dictionary codes stay valid: a code nobody carries any more is harmless. */
+int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                      const uint8_t *delete_flags, uint64_t *kept_out, void *stream);
+
 /* Tail of the all-gatherv merge.  A slot is what one rank's pqps_filter_scan produced when
  * given out_count = slot and out_ids = slot + PQPS_SLOT_HEADER_WORDS:
  *     [u64 match count][u64 reserved][u32 row IDs ...]

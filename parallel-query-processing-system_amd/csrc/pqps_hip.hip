@@ -146,6 +146,15 @@ __global__ __launch_bounds__(256) void merge_slots_kernel(const uint32_t *slots,
     }
 }
 
+// ---- DELETE support: keep-list gather ------------------------------------------------------------
+// dst[i] = src[keep[i]]; keep is ascending, so a wave's reads fall into a few neighbouring lines.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T *__restrict__ src, const uint32_t *__restrict__ keep,
+                                                          uint64_t n, T *__restrict__ dst) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = src[keep[i]];
+}
+
 // ---- INSERT support: shift dictionary codes at or above a new value's rank -----------------
 template <typename T>
 __global__ void bump_codes_kernel(T *codes, uint64_t n, uint32_t threshold) {
@@ -773,6 +782,60 @@ int pqps_bump_codes(pqps_ctx *ctx, void *codes, uint32_t width, uint64_t n_rows,
     else return fail(PQPS_EINVAL, "code width %u not in {1,2,4}", width);
     HIP_TRY(hipGetLastError());
     return PQPS_OK;
+}
+
+int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                      const uint8_t *delete_flags, uint64_t *kept_out, void *stream) {
+    if (!ctx || !cols || !delete_flags || !kept_out) return fail(PQPS_EINVAL, "NULL argument");
+    if (n_cols == 0 || n_cols > PQPS_MAX_COLUMNS) return fail(PQPS_EINVAL, "n_cols %u out of range", n_cols);
+    if (n_rows > 0xFFFFFFFFull) return fail(PQPS_EINVAL, "row IDs are u32");
+    for (uint32_t c = 0; c < n_cols; c++) {
+        const uint32_t w = cols[c].width;
+        if (!cols[c].data || (w != 1 && w != 2 && w != 4 && w != 8)) return fail(PQPS_EINVAL, "column %u: bad width / NULL data", c);
+    }
+    *kept_out = n_rows;
+    if (n_rows == 0) return PQPS_OK;
+    hipStream_t s = pick_stream(ctx, stream);
+    // keep list = ascending IDs of the rows whose flag is 0: the ordinary scan over a one-column table
+    pqps_column fcol = {delete_flags, 1, 0};
+    pqps_predicate keep_pred;
+    memset(&keep_pred, 0, sizeof keep_pred);
+    keep_pred.n_leaves = 1; keep_pred.n_columns = 1; keep_pred.truth = 0x2;
+    keep_pred.leaf[0].column = 0; keep_pred.leaf[0].lo = 0; keep_pred.leaf[0].span = 0;
+    keep_pred.on_true[0] = PQPS_ACCEPT; keep_pred.on_false[0] = PQPS_REJECT; keep_pred.order[0] = 0;
+    uint32_t *keep = nullptr;
+    uint64_t *count_dev = nullptr;
+    void *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&keep, n_rows * sizeof(uint32_t)));
+    hipError_t e = hipMalloc((void **)&count_dev, 64);
+    if (e == hipSuccess) e = hipMalloc(&tmp, n_rows * 8);
+    int rc = e == hipSuccess ? PQPS_OK : fail(PQPS_EHIP, "compaction scratch: %s", hipGetErrorString(e));
+    uint64_t kept = 0;
+    if (!rc) rc = pqps_filter_scan(ctx, &fcol, 1, n_rows, 0, &keep_pred, keep, n_rows, count_dev, (void *)s);
+    if (!rc) {
+        e = hipMemcpyAsync(&kept, count_dev, sizeof kept, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(PQPS_EHIP, "keep count: %s", hipGetErrorString(e));
+    }
+    if (!rc && kept < n_rows && kept > 0) {
+        const uint32_t grid = (uint32_t)((kept + 255) / 256 < (uint64_t)ctx->compute_units * 16 ? (kept + 255) / 256 : (uint64_t)ctx->compute_units * 16);
+        for (uint32_t c = 0; c < n_cols && !rc; c++) {
+            void *data = const_cast<void *>(cols[c].data);
+            switch (cols[c].width) {
+            case 1: hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t *)data, keep, kept, (uint8_t *)tmp); break;
+            case 2: hipLaunchKernelGGL(gather_rows_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t *)data, keep, kept, (uint16_t *)tmp); break;
+            case 4: hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, (const uint32_t *)data, keep, kept, (uint32_t *)tmp); break;
+            default: hipLaunchKernelGGL(gather_rows_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, (const uint64_t *)data, keep, kept, (uint64_t *)tmp); break;
+            }
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(data, tmp, kept * cols[c].width, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) rc = fail(PQPS_EHIP, "column %u compaction: %s", c, hipGetErrorString(e));
+        }
+        if (!rc && (e = hipStreamSynchronize(s)) != hipSuccess) rc = fail(PQPS_EHIP, "compaction: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(keep); (void)hipFree(count_dev); (void)hipFree(tmp);
+    if (!rc) *kept_out = kept;
+    return rc;
 }
 
 int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint64_t slot_stride,

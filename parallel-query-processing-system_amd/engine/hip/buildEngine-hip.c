@@ -531,6 +531,20 @@ void appendRowDeviceTableHIP(struct engineS *engine) {
     rebuild_indexes(engine, t);
 }
 
+/* DELETE: drops the flagged rows from the device columns in place and re-sorts the indexes. */
+void compactDeviceTableHIP(struct engineS *engine, const uint8_t *delete_flags_dev, size_t expected_rows) {
+    struct hipTable *t = engine->record_block;
+    uint64_t kept = 0;
+    if (pqps_compact_rows(t->ctx, t->col, HIPCOL_COUNT, t->n_rows, delete_flags_dev, &kept, NULL) != PQPS_OK)
+        hip_die("row compaction");
+    if (kept != (uint64_t)expected_rows) {
+        fprintf(stderr, "HIP engine: device kept %llu rows, host kept %zu\n", (unsigned long long)kept, expected_rows);
+        exit(EXIT_FAILURE);
+    }
+    t->n_rows = kept;
+    rebuild_indexes(engine, t);
+}
+
 void destroyDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = engine->record_block;
     if (!t) return;

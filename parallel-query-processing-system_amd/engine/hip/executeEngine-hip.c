@@ -415,7 +415,6 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     SHIM(pqps_filter_flags(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, flags_dev, t->count_dev, NULL), "flag filter");
     SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
     if (n) SHIM(pqps_download(t->ctx, flags, flags_dev, n, NULL), "flag download");
-    pqps_free(t->ctx, flags_dev);
 
     size_t keep = 0, deleted = 0;
     record *block = t->row_block;
@@ -433,7 +432,10 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
         for (size_t i = 0; i < keep; i++) write_csv_row(f, &block[i]);
         fclose(f);
     }
-    if (deleted) rebuildDeviceTableHIP(engine);
+    /* device side: the same flags compact the 12 columns in place (order kept); dictionaries
+     * stay as they are (a code without rows is harmless), indexes are re-sorted */
+    if (deleted) compactDeviceTableHIP(engine, flags_dev, keep);
+    pqps_free(t->ctx, flags_dev);
     rs->numRecords = (int)deleted;
     rs->queryTime = now_seconds() - t0;
     rs->success = true;

@@ -106,6 +106,31 @@ def test_insert_then_delete_roundtrip(tmp_path):
     assert rs.contents.numRecords == n0 - len(want)
     L.freeResultSet(rs)
     assert [eng.record(i).command_id for i in range(eng.e.contents.num_records)] == [orc.rows[i].command_id for i in want]
+    # the device columns were compacted in place (no rebuild): every query must answer exactly like an
+    # engine built from scratch over the surviving rows -- scan mode, index mode, strings, ranges
+    lines = (q.GOLDEN / "commands_2k.csv").read_bytes().split(b"\n")
+    body = [ln for ln in lines[1:] if ln.strip()]
+    fresh_csv = tmp_path / "survivors.csv"
+    fresh_csv.write_bytes(b"\n".join([lines[0]] + [body[i] for i in want]) + b"\n")
+    fresh = pq.HipEngine(fresh_csv, pq.DEFAULT_INDEXES)
+    assert fresh.n == eng.e.contents.num_records == len(want)
+    for chain in ([("risk_level", "<", "3")], [("user_id", ">=", "1100"), "AND", ("exit_code", "=", "0")],
+                  [("user_name", ">", "student1100"), "OR", ("shell_type", "=", "zsh")], [("sudo_used", "=", "TRUE")],
+                  [("command_id", "<", "50")], [("base_command", "=", "ls"), "AND", ("host_name", "<=", "labpc-08")],
+                  [("shell_type", "=", "fish")], [("risk_level", ">=", "4")], []):
+        assert eng.select_ids(chain) == fresh.select_ids(chain), chain
+        assert eng.count(chain) == fresh.count(chain)
+    got = eng.select(["command_id", "user_name", "raw_command"], [("exit_code", "!=", "0")])
+    ref = fresh.select(["command_id", "user_name", "raw_command"], [("exit_code", "!=", "0")])
+    assert got["rows"] == ref["rows"] and got["numRecords"] > 0
+    fresh.close()
+    # delete everything, then nothing
+    rs = L.executeQueryDeleteHIP(eng.e, b"Commands", pq.WhereList([("risk_level", "<", "4")]).ptr)
+    L.freeResultSet(rs)
+    assert eng.e.contents.num_records == 0 and eng.select_ids([]) == [] and eng.count([("risk_level", "=", "1")]) == 0
+    rs = L.executeQueryDeleteHIP(eng.e, b"Commands", pq.WhereList([]).ptr)
+    assert rs.contents.numRecords == 0
+    L.freeResultSet(rs)
     eng.close()
 
 

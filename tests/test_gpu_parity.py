@@ -245,6 +245,40 @@ def test_native_exchange_world_of_one(ctx):
         dev.free()
 
 
+def test_compact_rows_equals_numpy_boolean_indexing(ctx):
+    """pqps_compact_rows (DELETE on the device): flags from the predicate kernel, every column width
+    compacted in place, survivors in order -- numpy `col[~flags]` is the checker."""
+    rng = np.random.default_rng(3)
+    for n in (1, 4097, 300_001):
+        host = {1: rng.integers(0, 256, n, dtype=np.uint8), 2: rng.integers(0, 65536, n, dtype=np.uint16),
+                4: rng.integers(0, 2**32, n, dtype=np.uint32), 8: rng.integers(0, 2**63, n, dtype=np.uint64)}
+        pad = (n + 4095) // 4096 * 4096
+        bufs = {}
+        for w, arr in host.items():
+            bufs[w] = ctx.malloc(pad * w)
+            ctx.memset(bufs[w], 0, pad * w)
+            ctx.upload(bufs[w], arr.ctypes.data, arr.nbytes)
+        cols = pq.column_array([(bufs[w], w) for w in (8, 1, 4, 2)])
+        for flags in (rng.random(n) < 0.3, np.zeros(n, bool), np.ones(n, bool), np.arange(n) % 2 == 0):
+            for w, arr in host.items():
+                ctx.upload(bufs[w], arr.ctypes.data, arr.nbytes)
+            f8 = flags.astype(np.uint8)
+            fdev = ctx.malloc(pad)
+            ctx.memset(fdev, 0, pad)
+            ctx.upload(fdev, f8.ctypes.data, n)
+            kept = C.c_uint64()
+            pq.check(pq.lib().pqps_compact_rows(ctx.h, cols, 4, n, fdev, C.byref(kept), None), "pqps_compact_rows")
+            assert kept.value == int((~flags).sum())
+            for w, arr in host.items():
+                got = np.zeros(max(kept.value, 1), dtype=arr.dtype)
+                if kept.value:
+                    ctx.download(got.ctypes.data, bufs[w], kept.value * w)
+                assert np.array_equal(got[:kept.value], arr[~flags]), (n, w)
+            ctx.free(fdev)
+        for b_ in bufs.values():
+            ctx.free(b_)
+
+
 def test_bench_exchange_path_runs_on_one_gpu():
     """bench.py --force-merge: the N > 1 code path (torch.distributed bootstrap over RCCL, shim-driven
     all-gather + merge on the exchange stream, ring of slots) with a world of 1, in its own process
