@@ -329,7 +329,7 @@ def main():
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
     }
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)

@@ -259,6 +259,7 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
 int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
     if (!pred) return fail(PQPS_EINVAL, "predicate is NULL");
     if (n_cols > PQPS_MAX_COLUMNS) return fail(PQPS_EINVAL, "too many columns: %u", n_cols);
+    if (n_cols && !cols) return fail(PQPS_EINVAL, "column array is NULL");
     if (pred->n_leaves > PQPS_MAX_LEAVES) return fail(PQPS_EINVAL, "too many leaves: %u", pred->n_leaves);
     if (pred->n_columns != n_cols) return fail(PQPS_EINVAL, "predicate uses %u columns, call passes %u", pred->n_columns, n_cols);
     for (uint32_t c = 0; c < n_cols; c++) {

@@ -245,6 +245,61 @@ def test_native_exchange_world_of_one(ctx):
         dev.free()
 
 
+def test_shim_rejects_malformed_calls(ctx):
+    """Every shape the kernels assume is checked on the host first: a bad call returns PQPS_EINVAL
+    with a message and launches nothing (a kernel fault can take the whole GPU down)."""
+    L, EINVAL = pq.lib(), -1
+    dev = pq.SyntheticTable(ctx, 10_000, seed=2)
+    out = DeviceOut(ctx, 10_000)
+    pred, cols, nc, _ = dev.bind(QUERIES["Q_B"])
+
+    def scan(cols_=cols, nc_=nc, n=10_000, base=0, pred_=pred, ids=out.ids, cap=out.cap, cnt=out.count):
+        return L.pqps_filter_scan(ctx.h, cols_, nc_, n, base, C.byref(pred_) if pred_ is not None else None, ids, cap, cnt, None)
+
+    assert scan() == 0
+    assert scan(pred_=None) == EINVAL and b"predicate is NULL" in L.pqps_last_error()
+    assert scan(cnt=None) == EINVAL
+    assert scan(ids=None) == EINVAL
+    assert scan(cols_=None) == EINVAL
+    assert scan(nc_=nc + 1) == EINVAL                                 # predicate / call disagree on the column count
+    assert scan(n=2**32) == EINVAL and scan(n=10_000, base=2**32 - 5_000) == EINVAL      # u32 row IDs
+    assert L.pqps_filter_scan(None, cols, nc, 10, 0, C.byref(pred), out.ids, out.cap, out.count, None) == EINVAL
+
+    def mutated(fn):
+        p2 = pq.Predicate.from_buffer_copy(pred)
+        c2 = pq.column_array([(cols[i].data, cols[i].width) for i in range(nc)])
+        fn(p2, c2)
+        return scan(cols_=c2, pred_=p2)
+
+    assert mutated(lambda p, c: setattr(c[0], "width", 3)) == EINVAL
+    assert mutated(lambda p, c: setattr(c[0], "data", cols[0].data + 4)) == EINVAL          # 16-byte alignment
+    assert mutated(lambda p, c: setattr(c[1], "data", None)) == EINVAL
+    assert mutated(lambda p, c: setattr(p.leaf[0], "column", 7)) == EINVAL
+    assert mutated(lambda p, c: setattr(p.leaf[0], "negate", 2)) == EINVAL
+    assert mutated(lambda p, c: setattr(p, "n_leaves", 33)) == EINVAL
+
+    def swap_leaves(p, c):
+        p.leaf[0].column, p.leaf[1].column = 1, 0
+    assert mutated(swap_leaves) == EINVAL                                               # leaves sorted by column
+    # the jump program of a > 6-leaf predicate must only jump forward and name real leaf slots
+    pred7, cols7, nc7, _ = dev.bind(QUERIES["seven_leaves"])
+    for field, value in (("on_true", 0), ("on_false", 1), ("order", 9), ("on_true", 200)):
+        p7 = pq.Predicate.from_buffer_copy(pred7)
+        getattr(p7, field)[2] = value
+        assert L.pqps_filter_scan(ctx.h, cols7, nc7, 10_000, 0, C.byref(p7), out.ids, out.cap, out.count, None) == EINVAL, field
+    # count / flags / gather / index / merge entry points
+    assert L.pqps_filter_count(ctx.h, cols, nc, 10_000, C.byref(pred), None, None) == EINVAL
+    assert L.pqps_filter_flags(ctx.h, cols, nc, 10_000, C.byref(pred), None, out.count, None) == EINVAL
+    assert L.pqps_index_build(ctx.h, None, 10, 0, out.ids, out.ids, None) == EINVAL
+    assert L.pqps_compact_rows(ctx.h, cols, nc, 10, None, C.byref(C.c_uint64()), None) == EINVAL
+    assert L.pqps_compact_rows(ctx.h, cols, 0, 10, out.ids, C.byref(C.c_uint64()), None) == EINVAL
+    assert L.pqps_exchange_select(None, cols, nc, 10, 0, C.byref(pred), 0, None) == EINVAL
+    # a good call still works afterwards
+    assert np.array_equal(gpu_scan(ctx, dev, QUERIES["Q_B"], out), q.HostSynth(10_000, seed=2).oracle_scan(QUERIES["Q_B"]))
+    out.free()
+    dev.free()
+
+
 def test_compact_rows_equals_numpy_boolean_indexing(ctx):
     """pqps_compact_rows (DELETE on the device): flags from the predicate kernel, every column width
     compacted in place, survivors in order -- numpy `col[~flags]` is the checker."""
