@@ -195,7 +195,7 @@ def main():
         keep.append(t)
         return t.data_ptr()
 
-    extras = [] if args.no_extras else [k for k in QUERIES if k != args.query]
+    extras = [] if (args.no_extras or world > 1) else [k for k in QUERIES if k != args.query]
     needed = {leaf[0] for k in [args.query] + extras for leaf in _leaves(QUERIES[k][0])} & set(pq.COLUMNS)
     t0 = time.perf_counter()
     table = pq.SyntheticTable(ctx, count, seed=args.seed, row0=start, columns=sorted(needed), alloc=alloc, stream=sptr)
