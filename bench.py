@@ -408,6 +408,27 @@ def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log)
                                       "avg_kernel_ms": ms / k, "avg_pipeline_ms": pipe / k}
             log(f"{name:>4} {mode:>5}: {out[f'{name}_{mode}']['rows_per_s']/1e9:.1f} G rows/s, "
                 f"{out[f'{name}_{mode}']['GBps']:.0f} GB/s ({100*out[f'{name}_{mode}']['frac_of_8TBps']:.1f} % of 8 TB/s)")
+    # PCIe-inclusive, one blocking query at a time (what a host caller of the shim sees): scan, wait,
+    # read the count back, download the IDs into host memory.  Never `value`.
+    import numpy as np
+    main_q = [k for k in QUERIES if k not in names][0]
+    for name in [main_q] + [n for n in names if n == "Q_A"]:
+        chain, sql = QUERIES[name]
+        pred, cols, nc, bpr = table.bind(chain)
+        host_ids = np.empty(max(count, 1), dtype=np.uint32)
+        k_reps, m, got = 20, 0, C.c_uint64()
+        for i in range(k_reps + 3):
+            if i == 3:
+                t0 = time.perf_counter()
+            pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), ids.data_ptr(), count, cnt.data_ptr(), sptr))
+            ctx.download(C.byref(got), cnt.data_ptr(), 8, sptr)            # waits for the scan
+            m = got.value
+            if m:
+                ctx.download(host_ids.ctypes.data, ids.data_ptr(), 4 * m, sptr)
+        dt = (time.perf_counter() - t0) / k_reps
+        out[f"{name}_ids_to_host"] = {"query": sql, "matches": m, "ms_per_query": dt * 1e3, "rows_per_s": count / dt,
+                                      "note": "blocking: scan + sync + count readback + ID download (pageable host memory)"}
+        log(f"{name:>4} ids -> host: {dt * 1e6:.0f} us per query, {count / dt / 1e9:.1f} G rows/s (PCIe-inclusive)")
     # plain streaming-read ceiling (uint4 load + add), for context next to the 8 TB/s spec
     nbytes = 2 << 30
     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
