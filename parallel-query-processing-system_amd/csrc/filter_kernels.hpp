@@ -477,14 +477,30 @@ struct RawChunk {
     static constexpr int kBytes = W * RPL;                      // 32 (8-byte column), 16, 8 or 4
     static constexpr int kDwords = kBytes >= 4 ? kBytes / 4 : 1;
     uint32_t d[kDwords];
+    // NT: streaming hint (`nt` modifier) -- the lines are not kept in L2 / Infinity Cache.  Pays once
+    // the scan's footprint no longer fits the 256 MB Infinity Cache (measured crossover ~320 MB:
+    // +9..12 % on 0.4..3 GB scans, -2..5 % on <= 300 MB ones that a repeated query finds cached).
+    template <bool NT>
     __device__ __forceinline__ void load(const char *p) {
-        if constexpr (kBytes == 32) {
-            const uint4 q = *(const uint4 *)p, r = *(const uint4 *)(p + 16);
-            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; d[4] = r.x; d[5] = r.y; d[6] = r.z; d[7] = r.w;
-        } else if constexpr (kBytes == 16) { const uint4 q = *(const uint4 *)p; d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; }
-        else if constexpr (kBytes == 8) { const uint2 q = *(const uint2 *)p; d[0] = q.x; d[1] = q.y; }
-        else if constexpr (kBytes == 4) { d[0] = *(const uint32_t *)p; }
-        else { d[0] = *(const uint16_t *)p; }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (NT) {
+            if constexpr (kBytes == 32) {
+                const u32x4 q = __builtin_nontemporal_load((const u32x4 *)p), r = __builtin_nontemporal_load((const u32x4 *)(p + 16));
+                d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; d[4] = r.x; d[5] = r.y; d[6] = r.z; d[7] = r.w;
+            } else if constexpr (kBytes == 16) { const u32x4 q = __builtin_nontemporal_load((const u32x4 *)p); d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; }
+            else if constexpr (kBytes == 8) { const u32x2 q = __builtin_nontemporal_load((const u32x2 *)p); d[0] = q.x; d[1] = q.y; }
+            else if constexpr (kBytes == 4) { d[0] = __builtin_nontemporal_load((const uint32_t *)p); }
+            else { d[0] = __builtin_nontemporal_load((const uint16_t *)p); }
+        } else {
+            if constexpr (kBytes == 32) {
+                const uint4 q = *(const uint4 *)p, r = *(const uint4 *)(p + 16);
+                d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; d[4] = r.x; d[5] = r.y; d[6] = r.z; d[7] = r.w;
+            } else if constexpr (kBytes == 16) { const uint4 q = *(const uint4 *)p; d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w; }
+            else if constexpr (kBytes == 8) { const uint2 q = *(const uint2 *)p; d[0] = q.x; d[1] = q.y; }
+            else if constexpr (kBytes == 4) { d[0] = *(const uint32_t *)p; }
+            else { d[0] = *(const uint16_t *)p; }
+        }
     }
     template <int R>
     __device__ __forceinline__ uint32_t get32() const {          // row R of the chunk, W <= 4
@@ -499,9 +515,10 @@ struct RawChunk {
 template <int W, int RPL, int U>
 struct RawCol {
     RawChunk<W, RPL> c[U];
+    template <bool NT>
     __device__ __forceinline__ void load(const void *base, uint64_t lane_row0) {
 #pragma unroll
-        for (int u = 0; u < U; u++) c[u].load((const char *)base + (lane_row0 + (uint64_t)u * 64 * RPL) * W);
+        for (int u = 0; u < U; u++) c[u].template load<NT>((const char *)base + (lane_row0 + (uint64_t)u * 64 * RPL) * W);
     }
 };
 
@@ -565,10 +582,11 @@ struct RawStep {
     RawCol<W0, RPL, U> r0;
     RawCol<(W1 ? W1 : 1), RPL, U> r1;
     RawCol<(W2 ? W2 : 1), RPL, U> r2;
+    template <bool NT>
     __device__ __forceinline__ void load(const EvalArgs &a, uint64_t lane_row0) {
-        r0.load(a.col[0], lane_row0);
-        if constexpr (W1 != 0) r1.load(a.col[1], lane_row0);
-        if constexpr (W2 != 0) r2.load(a.col[2], lane_row0);
+        r0.template load<NT>(a.col[0], lane_row0);
+        if constexpr (W1 != 0) r1.template load<NT>(a.col[1], lane_row0);
+        if constexpr (W2 != 0) r2.template load<NT>(a.col[2], lane_row0);
     }
     __device__ __forceinline__ void eval_chain(const EvalArgs &a, RowPlanes &acc) const {
 #pragma unroll
@@ -590,7 +608,7 @@ struct RawStep {
 
 // W0 >= W1 >= W2 are the byte widths of the predicate columns (0 = slot unused).
 // General tree of <= 6 leaves (row-mask path), one step per iteration.
-template <int MODE, int W0, int W1, int W2>
+template <int MODE, int W0, int W1, int W2, bool NT>
 __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
@@ -606,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     uint64_t wave_total = 0;
     for (uint64_t step = wave; step < full_steps; step += n_waves) {
         RawStep<W0, W1, W2, RPL, U> A;
-        A.load(a, step * kStepRows + lane_off);
+        A.template load<NT>(a, step * kStepRows + lane_off);
         emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
     }
     // the partial last step (if any) goes through the guarded evaluator, RPL = 4 layout
@@ -619,11 +637,13 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
 
 // Chain predicates (AND of possibly complemented leaves, or the negation of one): SGPR planes.
 // A wave keeps the loads of S steps in flight (all S x columns loads are issued, then the steps
-// are evaluated one after the other): >= 4 KB per wave even for 1-byte columns -- HBM latency x
-// bandwidth needs > 100 KB in flight per CU.
-constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 >= 4 ? 1 : (w0 + w1 + w2 >= 2 ? 2 : 4); }
+// are evaluated one after the other).
+// Measured with streaming loads (1 B rows / 100 M rows, fraction of 8 TB/s): a lone 1-byte column needs
+// S = 4 (0.70 / 0.57 against 0.48 / 0.56 with S = 1: 1 KB per wave and step is too little in flight);
+// from 2 bytes per row on S = 1 is as good or better (u16 0.72 / 0.82 vs 0.72 / 0.80; u16+u8 0.71 vs 0.69).
+constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 4 : 1; }
 
-template <int MODE, int W0, int W1, int W2, int S>
+template <int MODE, int W0, int W1, int W2, int S, bool NT>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i * n_waves;
-            if (step < full_steps) A[i].load(a, step * kStepRows + lane_off);      // uniform guard
+            if (step < full_steps) A[i].template load<NT>(a, step * kStepRows + lane_off);      // uniform guard
         }
 #pragma unroll
         for (int i = 0; i < S; i++) {

@@ -337,13 +337,24 @@ typedef void (*eval_fn)(const EvalArgs);
     X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
 
 // chain kernels exist with 1 step per iteration and (narrow shapes) with several
-template <int MODE>
-eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step) {
-#define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return !chain ? eval_spec_kernel<MODE, A, B, C> \
-        : (multi_step ? eval_chain_kernel<MODE, A, B, C, chain_steps(A, B, C)> : eval_chain_kernel<MODE, A, B, C, 1>);
+template <int MODE, bool NT>
+eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step) {
+#define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return !chain ? eval_spec_kernel<MODE, A, B, C, NT> \
+        : (multi_step ? eval_chain_kernel<MODE, A, B, C, chain_steps(A, B, C), NT> : eval_chain_kernel<MODE, A, B, C, 1, NT>);
     PQPS_FOR_EACH_SHAPE(X)
 #undef X
     return nullptr;
+}
+
+// Streaming (`nt`) loads once the columns read by the query outgrow the Infinity Cache (256 MB on
+// MI355X) by a margin; below that a repeated scan finds part of the table cached and plain loads win.
+constexpr uint64_t kStreamingFootprint = 320ull << 20;
+
+template <int MODE>
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, uint64_t footprint) {
+    static const char *force = getenv("PQPS_NT_LOADS");
+    const bool nt = force ? atoi(force) != 0 : footprint > kStreamingFootprint;
+    return nt ? find_spec_nt<MODE, true>(w0, w1, w2, chain, multi_step) : find_spec_nt<MODE, false>(w0, w1, w2, chain, multi_step);
 }
 
 // `a` must already carry the chain classification of fill_args().
@@ -351,10 +362,10 @@ template <int MODE>
 eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred, const EvalArgs &a, uint64_t n_rows) {
     if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1 && pred->n_leaves <= PQPS_TT_LEAVES) {
         const uint32_t w0 = cols[0].width, w1 = n_cols > 1 ? cols[1].width : 0, w2 = n_cols > 2 ? cols[2].width : 0;
-        // several steps per iteration pay off once a wave has many steps to stream
+        // several steps per iteration only where chain_steps() says so (a lone 1-byte column)
         static const char *force = getenv("PQPS_CHAIN_MULTI");
-        const bool multi = force ? atoi(force) != 0 : n_rows >= (1ull << 28);
-        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi)) return f;   // nullptr unless widths are non-increasing
+        const bool multi = force ? atoi(force) != 0 : true;
+        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, n_rows * (w0 + w1 + w2))) return f;   // nullptr unless widths are non-increasing
     }
     return eval_generic_kernel<MODE, false>;
 }

@@ -141,7 +141,7 @@ int main() {
         const int reps = 30;
         for (int i = 0; i < reps + 3; i++) {
             CK(hipEventRecord(e0, s));
-            hipLaunchKernelGGL((eval_spec_kernel<MODE_IDS, 4, 0, 0>), dim3(4096), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((eval_spec_kernel<MODE_IDS, 4, 0, 0, false>), dim3(4096), dim3(256), 0, s, a);
             CK(hipEventRecord(e1, s));
             hipLaunchKernelGGL(group_sum_kernel, dim3((uint32_t)((groups + 3) / 4)), dim3(256), 0, s, sa);
             CK(hipEventRecord(e2, s));
