@@ -197,6 +197,8 @@ def main():
 
     extras = [] if (args.no_extras or world > 1) else [k for k in QUERIES if k != args.query]
     needed = {leaf[0] for k in [args.query] + extras for leaf in _leaves(QUERIES[k][0])} & set(pq.COLUMNS)
+    if extras:
+        needed |= {"command_id", "user_id", "risk_level"}          # index-mode leg (configs[2])
     t0 = time.perf_counter()
     table = pq.SyntheticTable(ctx, count, seed=args.seed, row0=start, columns=sorted(needed), alloc=alloc, stream=sptr)
     torch.cuda.synchronize()
@@ -408,6 +410,50 @@ def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log)
                                       "avg_kernel_ms": ms / k, "avg_pipeline_ms": pipe / k}
             log(f"{name:>4} {mode:>5}: {out[f'{name}_{mode}']['rows_per_s']/1e9:.1f} G rows/s, "
                 f"{out[f'{name}_{mode}']['GBps']:.0f} GB/s ({100*out[f'{name}_{mode}']['frac_of_8TBps']:.1f} % of 8 TB/s)")
+    # ---- configs[2]: index range-probe SELECT (sorted-permutation index = B+-tree leaf order) --------
+    # bytes per SURVEY 8(d): slice_len * (4 [perm] + sum of gathered predicate column widths) + 4 * matches
+    have = set(table.ptr)
+    specs = [("command_id", 0, "command_id >= n-1e6", [("command_id", ">=", str(start + count - 1_000_000))], start + count - 1_000_000, 2**64 - 1),
+             ("user_id", 1, "user_id = 1001", [("user_id", "=", "1001")], 1001, 1001),
+             ("risk_level", 1, "risk_level = 5", [("risk_level", "=", "5")], 5, 5)]
+    rng = torch.zeros(4, dtype=torch.int64, device=device)
+    for col, kind, label, chain, lo, hi in specs:
+        if col not in have:
+            continue
+        w = table.width[col]
+        perm = torch.empty(count, dtype=torch.int32, device=device)
+        keys = torch.empty(count * w, dtype=torch.uint8, device=device)
+        carr = pq.column_array([(table.ptr[col], w)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pq.check(L.pqps_index_build(ctx.h, carr, count, kind, perm.data_ptr(), keys.data_ptr(), sptr), "pqps_index_build")
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        pred, cols, nc, bpr = table.bind(chain)
+
+        def probe():
+            cnt.zero_()
+            pq.check(L.pqps_index_probe(ctx.h, keys.data_ptr(), w, kind, count, lo & (2**64 - 1), hi & (2**64 - 1), rng.data_ptr(), sptr), "probe")
+            pq.check(L.pqps_filter_gather(ctx.h, cols, nc, perm.data_ptr(), rng.data_ptr(), count, start, C.byref(pred),
+                                          ids.data_ptr(), count, cnt.data_ptr(), sptr), "gather")
+        for _ in range(3):
+            probe()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            probe()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        slice_len = int(rng[1].item() - rng[0].item())
+        matches = int(cnt[0].item())
+        byts = slice_len * (4 + bpr) + 4 * matches
+        out[f"index_{col}"] = {"query": label, "index_build_ms": build_ms, "ms_per_query": ms, "slice_len": slice_len,
+                               "matches": matches, "GBps": byts / (ms * 1e-3) / 1e9,
+                               "rows_per_s_table": count / (ms * 1e-3)}
+        log(f"index {label}: build {build_ms:.1f} ms, probe+filter {ms * 1e3:.0f} us, slice {slice_len:,}, {matches:,} matches")
+        del perm, keys
     # PCIe-inclusive, one blocking query at a time (what a host caller of the shim sees): scan, wait,
     # read the count back, download the IDs into host memory.  Never `value`.
     import numpy as np

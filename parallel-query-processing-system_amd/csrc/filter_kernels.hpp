@@ -457,10 +457,12 @@ __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) 
         n_rows = end > begin ? end - begin : 0;
         if (n_rows > a.n_rows) n_rows = a.n_rows;               // never past the caller's bound
     }
-    // gather: the host sized counts[] for a.n_rows; steps past the device-side range report 0
-    const uint64_t steps_alloc = (a.n_rows + kStepRows - 1) / kStepRows;
+    // gather: the host sized the launch and counts[] for a.n_rows candidates, but only the steps of the
+    // device-side range are evaluated (K2 / K3 derive the same bound): a narrow probe costs three
+    // near-empty launches, not a pass over the whole table's step array
+    const uint64_t steps_used = (n_rows + kStepRows - 1) / kStepRows;
     uint64_t wave_total = 0;
-    for (uint64_t step = wave; step < steps_alloc; step += n_waves) {
+    for (uint64_t step = wave; step < steps_used; step += n_waves) {
         const uint64_t step_row0 = step * kStepRows;
         uint32_t mbits = 0;
         if (!GATHER && step_row0 + kStepRows <= n_rows) mbits = eval_step_full(a, step_row0, lane);
@@ -694,15 +696,27 @@ struct SumArgs {
     uint64_t *base_slot;             // scratch: first output slot of this query
     const uint64_t *out_count;       // device result counter (read when accumulate)
     int accumulate;                  // 1: IDs are appended after *out_count (index probes)
+    const uint64_t *range;           // gather: device-side candidate range (else nullptr)
+    uint64_t max_rows;               // gather: the caller's bound on the range length
 };
+
+// Steps K1 evaluated in gather mode (same clamp as eval_generic_kernel).
+__device__ __forceinline__ uint64_t gather_steps(const uint64_t *range, uint64_t max_rows) {
+    const uint64_t b = range[0], e = range[1];
+    uint64_t n = e > b ? e - b : 0;
+    if (n > max_rows) n = max_rows;
+    return (n + kStepRows - 1) / kStepRows;
+}
 
 __global__ __launch_bounds__(kBlock) void group_sum_kernel(const SumArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.base_slot = a.accumulate ? *a.out_count : 0;
-    for (uint64_t group = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); group < a.groups;
+    const uint64_t steps = a.range ? gather_steps(a.range, a.max_rows) : a.steps;
+    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+    for (uint64_t group = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); group < groups;
          group += (uint64_t)gridDim.x * kWaves) {
         const uint64_t step = group * kGroupSteps + lane;
-        const uint32_t c = step < a.steps ? (a.counts[step] & 0x0FFFFFFFu) : 0u;
+        const uint32_t c = step < steps ? (a.counts[step] & 0x0FFFFFFFu) : 0u;
         const uint32_t sum = wave_sum_u32(c);
         if (lane == 0) {
             a.group_sum[group] = sum;
@@ -740,6 +754,7 @@ struct ExpandArgs {
     uint64_t out_cap;
     const uint32_t *cand;            // gather: candidate list
     const uint64_t *range;
+    uint64_t max_rows;               // gather: the caller's bound on the range length
     uint32_t id_base;
     uint32_t gather;
 };
@@ -771,11 +786,21 @@ __device__ __forceinline__ void expand_step(const ExpandArgs &a, uint64_t step, 
     const uint32_t incl = wave_incl_scan_u32(cnt);
     uint32_t pos = incl - cnt;
     const uint32_t r0 = (uint32_t)(step * kStepRows) + lane * 16u;
-    while (word) {                                                  // set bits only, ascending rows
-        const uint32_t j = (uint32_t)__builtin_ctz(word);
-        word &= word - 1;
-        const uint32_t id = a.gather ? a.cand[begin + r0 + j] : r0 + j;
-        stage[pos++] = id + a.id_base;
+    if (a.gather) {                                                 // uniform
+        // candidate numbers of the set bits, all requested before any is used (one memory latency per
+        // step, not one per ID); a set bit implies the row lies inside the probed range
+        uint32_t c[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) c[j] = ((word >> j) & 1u) ? a.cand[begin + r0 + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++)
+            if ((word >> j) & 1u) stage[pos++] = c[j] + a.id_base;
+    } else {
+        while (word) {                                              // set bits only, ascending rows
+            const uint32_t j = (uint32_t)__builtin_ctz(word);
+            word &= word - 1;
+            stage[pos++] = r0 + j + a.id_base;
+        }
     }
     // same wave wrote and reads: DS operations of one wave complete in order; the asm only
     // stops the compiler from moving the reads above the writes
@@ -808,22 +833,30 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t begin = a.gather ? a.range[0] : 0;
     const uint64_t base0 = *a.base_slot;
-    for (uint64_t group = blockIdx.x; group < a.groups; group += gridDim.x) {
+    const uint64_t steps = a.gather ? gather_steps(a.range, a.max_rows) : a.steps;
+    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+    // few groups (a narrow index probe, a small table): split each over `parts` workgroups, every one
+    // expanding 64 / parts of the group's steps, so that the work still spreads over the chip
+    const uint32_t parts = groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u);
+    const uint32_t slots = (kGroupSteps / kWaves) / parts;            // step slots per wave: 16, 4 or 1
+    for (uint64_t v = blockIdx.x; v < groups * parts; v += gridDim.x) {
+        const uint64_t group = v / parts;
+        const uint32_t part = (uint32_t)(v % parts);
         // (1) counts of the 64 steps (every wave loads the same 256 bytes) + the sums in front
         const uint64_t my_step = group * kGroupSteps + lane;
-        const uint32_t cw = my_step < a.steps ? a.counts[my_step] : 0u;
+        const uint32_t cw = my_step < steps ? a.counts[my_step] : 0u;
         const uint64_t sg = group / kSuperGroups, g_in = group % kSuperGroups;
-        uint32_t part = 0;                                          // < 2^32: row IDs are u32
-        for (uint64_t j = tid; j < sg; j += kBlock) part += (uint32_t)a.super_sum[j * kSuperStride];
-        if (tid < g_in) part += a.group_sum[sg * kSuperGroups + tid];
+        uint32_t psum = 0;                                          // < 2^32: row IDs are u32
+        for (uint64_t j = tid; j < sg; j += kBlock) psum += (uint32_t)a.super_sum[j * kSuperStride];
+        if (tid < g_in) psum += a.group_sum[sg * kSuperGroups + tid];
         const uint32_t my_cnt = cw & 0x0FFFFFFFu;
         const uint64_t nonempty = __ballot(my_cnt != 0);
-        const bool last_group = group + 1 == a.groups;
+        const bool last_group = group + 1 == groups;
         if (nonempty == 0 && !last_group) continue;                 // uniform for the workgroup
         // (2) matches before this group
-        part = wave_sum_u32(part);
+        psum = wave_sum_u32(psum);
         __syncthreads();                                            // previous iteration done with s_part
-        if (lane == 0) s_part[wave] = part;
+        if (lane == 0) s_part[wave] = psum;
         __syncthreads();
         uint64_t group_off = base0;
 #pragma unroll
@@ -831,23 +864,24 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
         // (3) exclusive prefix of the step counts inside the group
         const uint32_t incl = wave_incl_scan_u32(my_cnt);
         const uint64_t my_off = group_off + (incl - my_cnt);
-        if (last_group && wave == 0 && lane == 63) *a.out_count = group_off + incl;
-        // (4) wave w owns steps w, w+4, ... of the group.  All their match-bit words are
-        // requested at once (one memory latency for up to 16 steps), parked in LDS, then expanded.
+        if (last_group && part == 0 && wave == 0 && lane == 63) *a.out_count = group_off + incl;
+        // (4) wave w owns steps w, w+4, ... of the group (slot i <-> step w + 4i); this workgroup takes
+        // the slots [part * slots, (part + 1) * slots).  All their match-bit words are requested at
+        // once (one memory latency for up to 16 steps), parked in LDS, then expanded.
         const uint16_t *gmask = a.masks + (group * kGroupSteps + wave) * 64 + lane;
+        const uint32_t slot0 = part * slots, slot1 = slot0 + slots;
         uint32_t mreg[kGroupSteps / kWaves];
 #pragma unroll
-        for (int i = 0; i < kGroupSteps / kWaves; i++) {
+        for (uint32_t i = 0; i < kGroupSteps / kWaves; i++) {
             mreg[i] = 0;
-            if ((nonempty >> (wave + kWaves * i)) & 1ull) mreg[i] = gmask[(size_t)i * kWaves * 64];   // uniform branch
+            if (i >= slot0 && i < slot1 && ((nonempty >> (wave + kWaves * i)) & 1ull)) mreg[i] = gmask[(size_t)i * kWaves * 64];   // uniform branch
         }
 #pragma unroll
-        for (int i = 0; i < kGroupSteps / kWaves; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
+        for (uint32_t i = 0; i < kGroupSteps / kWaves; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint64_t mine = nonempty >> wave;                           // bit 4i <-> my slot i
-        for (int i = 0; i < kGroupSteps / kWaves; i++, mine >>= kWaves) {
-            if (!(mine & 1ull)) continue;
-            const int sidx = (int)wave + kWaves * i;
+        for (uint32_t i = slot0; i < slot1; i++) {
+            const int sidx = (int)(wave + kWaves * i);
+            if (!((nonempty >> sidx) & 1ull)) continue;
             const uint64_t step_off = __shfl(my_off, sidx, 64);
             const uint32_t cwi = (uint32_t)__shfl((int)cw, sidx, 64);
             expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,

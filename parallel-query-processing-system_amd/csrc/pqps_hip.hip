@@ -37,16 +37,34 @@ __global__ void reverse_gather_kernel(const K *col, uint64_t n, K *keys_rev, uin
 template <typename K>
 __device__ __forceinline__ bool key_less(K a, K b) { return a < b; }
 
+// One wave, 64-ary search: every round the 64 lanes test the last key of 64 equal chunks of the
+// remaining interval, so 100 M keys take 5-6 dependent loads instead of 27 (both bounds at once).
+//   range[0] = first position with key >= lo, range[1] = first position with key > hi
 template <typename K>
-__global__ void probe_kernel(const K *keys, uint64_t n, K lo, K hi, uint64_t *range) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t l = 0, r = n;
-    while (l < r) { const uint64_t m = l + (r - l) / 2; if (keys[m] < lo) l = m + 1; else r = m; }
-    const uint64_t b = l;
-    r = n;
-    while (l < r) { const uint64_t m = l + (r - l) / 2; if (!(hi < keys[m])) l = m + 1; else r = m; }
-    range[0] = b;
-    range[1] = l < b ? b : l;
+__global__ __launch_bounds__(64) void probe_kernel(const K *keys, uint64_t n, K lo, K hi, uint64_t *range) {
+    const uint64_t lane = threadIdx.x;
+    uint64_t l0 = 0, r0 = n, l1 = 0, r1 = n;                   // invariant: answer in [l, r]
+    while (l0 < r0 || l1 < r1) {                               // uniform
+        const uint64_t len0 = r0 - l0, len1 = r1 - l1;
+        const uint64_t c0 = (len0 + 63) / 64, c1 = (len1 + 63) / 64;
+        const uint64_t p0 = l0 + (lane + 1) * c0 - 1, p1 = l1 + (lane + 1) * c1 - 1;
+        bool t0 = true, t1 = true;                             // positions >= r count as "true"
+        if (len0 && p0 < r0) t0 = !(keys[p0] < lo);
+        if (len1 && p1 < r1) t1 = hi < keys[p1];
+        const uint64_t b0 = __ballot(t0), b1 = __ballot(t1);
+        if (len0) {
+            if (!b0) l0 = r0;
+            else { const uint64_t f = (uint64_t)__builtin_ctzll(b0), q = l0 + (f + 1) * c0 - 1; l0 += f * c0; r0 = q < r0 ? q : r0; }
+        }
+        if (len1) {
+            if (!b1) l1 = r1;
+            else { const uint64_t f = (uint64_t)__builtin_ctzll(b1), q = l1 + (f + 1) * c1 - 1; l1 += f * c1; r1 = q < r1 ? q : r1; }
+        }
+    }
+    if (lane == 0) {
+        range[0] = l0;
+        range[1] = l1 < l0 ? l0 : l1;
+    }
 }
 
 // ---- synthetic generator ---------------------------------------------------
@@ -412,6 +430,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         sa.counts = ctx->counts; sa.steps = steps; sa.groups = groups;
         sa.group_sum = ctx->group_sum; sa.super_sum = ctx->super_sum; sa.base_slot = ctx->base_slot;
         sa.out_count = out_count; sa.accumulate = gather ? 1 : 0;
+        sa.range = gather ? a.range : nullptr; sa.max_rows = rows;
         uint64_t sum_blocks = (groups + kWaves - 1) / kWaves;
         if (sum_blocks > 2048) sum_blocks = 2048;
         hipLaunchKernelGGL(group_sum_kernel, dim3((uint32_t)(sum_blocks ? sum_blocks : 1)), dim3(kBlock), 0, s, sa);
@@ -420,10 +439,13 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         ea.masks = ctx->masks; ea.counts = ctx->counts; ea.group_sum = ctx->group_sum; ea.super_sum = ctx->super_sum;
         ea.base_slot = ctx->base_slot; ea.out_count = out_count;
         ea.steps = steps; ea.groups = groups; ea.out_ids = out_ids; ea.out_cap = out_cap;
-        ea.cand = a.cand; ea.range = a.range; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
+        ea.cand = a.cand; ea.range = a.range; ea.max_rows = rows; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
         if (groups) {
             const uint64_t cap = (uint64_t)ctx->compute_units * 32;
-            const dim3 eg((uint32_t)(groups < cap ? groups : cap));
+            // few groups are split over up to 16 workgroups each (expand_kernel derives `parts` from the
+            // group count it sees on the device, which in gather mode can be smaller than this bound)
+            const uint64_t vgroups = groups * (groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u));
+            const dim3 eg((uint32_t)(vgroups < cap ? vgroups : cap));
             if (done) hipExtLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, nullptr, done, 0, ea);
             else hipLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, ea);
             HIP_TRY(hipGetLastError());
