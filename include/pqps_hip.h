@@ -24,6 +24,12 @@
  *                       leaf order of engine/bplus.c:282-314,471-490.
  *   pqps_index_probe    findLeaf + the leaf walk of findRange (bplus.c:282-358).
  *   pqps_partition      the block partition of engine/mpi/executeEngine-mpi.c:703-715.
+ *   pqps_exchange_*     the per-query exchange of the MPI engine (executeEngine-mpi.c:717-768:
+ *                       local scan of the rank's rows, MPI_Allgather + MPI_Allgatherv; :745
+ *                       MPI_Allreduce for counts) as shard scan + ONE RCCL collective.
+ *   pqps_merge_slots    the displacement arithmetic + placement of MPI_Allgatherv (:758-765).
+ *   pqps_compact_rows   the survivor compaction of DELETE (executeEngine-serial.c:645-676).
+ *   pqps_bump_codes     (no counterpart: keeps dictionary codes order-preserving on INSERT).
  *
  * All functions return 0 on success or a negative PQPS_E* code; the text of
  * the last error of the calling thread is at pqps_last_error().
@@ -92,17 +98,19 @@ typedef struct pqps_ctx pqps_ctx;
 
 const char *pqps_last_error(void);
 
-/* Context = device ordinal + stream + look-back scratch (grown on demand). */
+/* Context = device ordinal + stream + filter scratch (match bits, step / group / supergroup
+ * counts; grown on demand).  One query at a time per context; use one context per host thread. */
 int  pqps_ctx_create(int device, pqps_ctx **out);
 void pqps_ctx_destroy(pqps_ctx *ctx);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
-/* Per-launch HIP-event timing of the filter (events recorded on the launch
- * stream, up to 4096 launches per reset).  pqps_ctx_kernel_time waits for the
- * recorded launches and returns: *eval_ms = sum of the durations of the
- * evaluate kernel alone (K1, the only kernel that reads the table),
- * *total_ms = sum over the whole K1 -> K2 -> K3 pipeline, and their number;
- * it then resets the recorder. */
+/* Per-launch HIP-event timing of the filter (up to 4096 launches per reset).
+ * The evaluate kernel (K1, the only kernel that reads the table) carries its
+ * own begin / end events on the dispatch packet, i.e. the timestamps rocprofv3
+ * --kernel-trace reports; a third event is recorded after the last kernel.
+ * pqps_ctx_kernel_time waits for the recorded launches and returns: *eval_ms =
+ * sum of the K1 durations, *total_ms = sum over the whole K1 -> K2 -> K3
+ * pipeline, and their number; it then resets the recorder. */
 int  pqps_ctx_set_timing(pqps_ctx *ctx, int enable);
 int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *launches);
 /* Fills name (<=63 chars), CU count and total HBM bytes of the ctx device. */
