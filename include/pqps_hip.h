@@ -28,7 +28,7 @@
  *                       local scan of the rank's rows, MPI_Allgather + MPI_Allgatherv; :745
  *                       MPI_Allreduce for counts) as shard scan + ONE RCCL collective.
  *   pqps_merge_slots    the displacement arithmetic + placement of MPI_Allgatherv (:758-765).
- *   pqps_compact_rows   the survivor compaction of DELETE (executeEngine-serial.c:645-676).
+ *   pqps_compact_rows   the survivor compaction of DELETE (executeEngine-serial.c:646-680).
  *   pqps_bump_codes     (no counterpart: keeps dictionary codes order-preserving on INSERT).
  *
  * All functions return 0 on success or a negative PQPS_E* code; the text of
@@ -171,7 +171,7 @@ int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int
                      uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
                      uint64_t *range, void *stream);
 
-/* DELETE on the device (engine/serial/executeEngine-serial.c:645-676 removes the matching rows and
+/* DELETE on the device (engine/serial/executeEngine-serial.c:646-680 removes the matching rows and
  * keeps the survivors in order): `delete_flags` is what pqps_filter_flags produced (1 = row goes).
  * Every column is compacted in place to the surviving rows, order preserved; *kept_out = survivors.
  * Synchronises the stream.  Dictionary codes stay valid: a code nobody carries any more is harmless. */
