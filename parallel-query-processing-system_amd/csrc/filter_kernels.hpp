@@ -757,6 +757,7 @@ struct ExpandArgs {
     uint64_t max_rows;               // gather: the caller's bound on the range length
     uint32_t id_base;
     uint32_t gather;
+    uint64_t wave_groups_min;        // from this many groups on: one group per WAVE (see expand_kernel)
 };
 
 constexpr int kStageIds = kStepRows;        // a step yields at most 1024 IDs
@@ -835,6 +836,57 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
     const uint64_t base0 = *a.base_slot;
     const uint64_t steps = a.gather ? gather_steps(a.range, a.max_rows) : a.steps;
     const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+    if (groups >= a.wave_groups_min) {                                // uniform for the grid
+        // very many groups (>= 0.5 G rows): a group per WAVE.  The per-group chain of dependent loads
+        // (sums in front -> counts -> match words -> IDs) is latency, not work; with four times as
+        // many groups in flight the same chip finishes in a quarter of the rounds.  No barriers.
+        for (uint64_t group = (uint64_t)blockIdx.x * kWaves + wave; group < groups; group += (uint64_t)gridDim.x * kWaves) {
+            const uint64_t my_step = group * kGroupSteps + lane;
+            const uint32_t cw = my_step < steps ? a.counts[my_step] : 0u;
+            const uint64_t sg = group / kSuperGroups, g_in = group % kSuperGroups;
+            uint32_t psum = 0;
+            for (uint64_t j = lane; j < sg; j += 256) {              // four independent loads per trip
+                const uint64_t j1 = j + 64, j2 = j + 128, j3 = j + 192;
+                const unsigned long long s0 = a.super_sum[j * kSuperStride];
+                const unsigned long long s1 = j1 < sg ? a.super_sum[j1 * kSuperStride] : 0ull;
+                const unsigned long long s2 = j2 < sg ? a.super_sum[j2 * kSuperStride] : 0ull;
+                const unsigned long long s3 = j3 < sg ? a.super_sum[j3 * kSuperStride] : 0ull;
+                psum += (uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3;
+            }
+            if (lane < g_in) psum += a.group_sum[sg * kSuperGroups + lane];
+            const uint32_t my_cnt = cw & 0x0FFFFFFFu;
+            const uint64_t nonempty = __ballot(my_cnt != 0);
+            const bool last_group = group + 1 == groups;
+            if (nonempty == 0 && !last_group) continue;             // uniform for the wave
+            const uint64_t group_off = base0 + wave_sum_u32(psum);
+            const uint32_t incl = wave_incl_scan_u32(my_cnt);
+            const uint64_t my_off = group_off + (incl - my_cnt);
+            if (last_group && lane == 63) *a.out_count = group_off + incl;
+            const uint16_t *gmask = a.masks + group * kGroupSteps * 64 + lane;
+            for (uint32_t c = 0; c < kGroupSteps; c += 16) {          // 16 consecutive steps at a time
+                const uint32_t bits = (uint32_t)(nonempty >> c) & 0xFFFFu;
+                if (!bits) continue;
+                uint32_t mreg[16];
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    mreg[i] = 0;
+                    if ((bits >> i) & 1u) mreg[i] = gmask[(size_t)(c + i) * 64];                          // uniform branch
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (uint32_t i = 0; i < 16; i++) {
+                    if (!((bits >> i) & 1u)) continue;
+                    const int sidx = (int)(c + i);
+                    const uint64_t step_off = __shfl(my_off, sidx, 64);
+                    const uint32_t cwi = (uint32_t)__shfl((int)cw, sidx, 64);
+                    expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
+                                    cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
+                }
+            }
+        }
+        return;
+    }
     // few groups (a narrow index probe, a small table): split each over `parts` workgroups, every one
     // expanding 64 / parts of the group's steps, so that the work still spreads over the chip
     const uint32_t parts = groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u);

@@ -444,7 +444,12 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
             const uint64_t cap = (uint64_t)ctx->compute_units * 32;
             // few groups are split over up to 16 workgroups each (expand_kernel derives `parts` from the
             // group count it sees on the device, which in gather mode can be smaller than this bound)
-            const uint64_t vgroups = groups * (groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u));
+            static const char *wg_env = getenv("PQPS_K3_WAVE_GROUPS");
+            ea.wave_groups_min = wg_env ? strtoull(wg_env, nullptr, 10) : 8192;
+            // (in gather mode the device may see fewer groups than this bound and pick another mode:
+            // every mode loops over its work with the grid it is given)
+            const uint64_t vgroups = groups >= ea.wave_groups_min ? (groups + kWaves - 1) / kWaves
+                                   : groups * (groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u));
             const dim3 eg((uint32_t)(vgroups < cap ? vgroups : cap));
             if (done) hipExtLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, nullptr, done, 0, ea);
             else hipLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, ea);
