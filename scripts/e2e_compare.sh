@@ -1,10 +1,10 @@
 #!/bin/bash
 # End-to-end: the real reference driver (oracle/_ref/QPESeq_ref) vs QPEHIP on the same synthetic CSV and
-# the reference's sample-queries.txt.  usage: scripts/e2e_compare.sh <rows>
+# the reference's sample-queries.txt (QUERIES=sample-queries-FULL.txt for the file with the DELETE).  usage: scripts/e2e_compare.sh <rows>
 rows=${1:-1000000}
 work=$(mktemp -d)
 python3 $GRAFT_REPO_ROOT/scripts/make_csv.py $rows $work/data.csv
-cp $GRAFT_REPO_ROOT/tests/golden/sample-queries.txt $work/
+cp $GRAFT_REPO_ROOT/tests/golden/${QUERIES:-sample-queries.txt} $work/sample-queries.txt
 cd $work
 cp data.csv data_ref.csv; cp data.csv data_hip.csv
 echo "== QPESeq (reference, 1 core)"; ( time $GRAFT_REPO_ROOT/oracle/_ref/QPESeq_ref data_ref.csv > ref.out ) 2>&1 | grep real; grep -a -E "Initialization|Query Execution|Total Execution" ref.out | sed 's/\x1b\[[0-9;]*m//g'

@@ -332,24 +332,38 @@ def main():
     eng.close()
     (HERE / "print_golden.json").write_text(json.dumps(prt, indent=0))
 
-    # ---- end-to-end driver golden: the reference's QPESeq on its own sample-queries.txt -----
-    # (the INSERT of Sample 5 appends to the CSV, so the run works on a scratch copy)
-    import re
-    import shutil
-    qpeseq = q.ORACLE_DIR / "_ref" / "QPESeq_ref"
-    sample = HERE / "sample-queries.txt"
-    if not sample.exists():
-        shutil.copy("/root/reference/sample-queries.txt", sample)        # input data file of the reference
-    with tempfile.TemporaryDirectory() as td:
-        shutil.copy(csv2k, pathlib.Path(td) / "data.csv")
-        shutil.copy(sample, pathlib.Path(td) / "sample-queries.txt")
-        out = subprocess.run([str(qpeseq), "data.csv"], cwd=td, capture_output=True, check=True).stdout.decode("latin-1")
-    (HERE / "qpeseq_stdout.txt").write_text(normalize_driver_output(out), encoding="latin-1")
+    driver_goldens(csv2k)
 
     unpinned = [c["name"] + "/" + c["indexes"] for c in sel_out if not c["pinned"]]
     print(f"select cases: {len(sel_out)} ({len(unpinned)} not sent to the reference: {unpinned})")
     print(f"parse cases: {len(parse_out)}")
 
 
+def driver_goldens(csv2k):
+    """End-to-end driver goldens: the reference's QPESeq on its own sample-queries.txt and
+    sample-queries-FULL.txt (which adds Sample 6, the DELETE).  The driver always opens
+    "sample-queries.txt" in its working directory (QPESeq.c:40); INSERT appends to the CSV and DELETE
+    rewrites it, so every run works on a scratch copy, and the CSV the run leaves behind is part of
+    the golden (as a SHA-256)."""
+    import hashlib
+    import shutil
+    qpeseq = q.ORACLE_DIR / "_ref" / "QPESeq_ref"
+    for src, out_name in (("sample-queries.txt", "qpeseq_stdout.txt"), ("sample-queries-FULL.txt", "qpeseq_full_stdout.txt")):
+        sample = HERE / src
+        if not sample.exists():
+            shutil.copy("/root/reference/" + src, sample)                   # input data file of the reference
+        with tempfile.TemporaryDirectory() as td:
+            shutil.copy(csv2k, pathlib.Path(td) / "data.csv")
+            shutil.copy(sample, pathlib.Path(td) / "sample-queries.txt")
+            out = subprocess.run([str(qpeseq), "data.csv"], cwd=td, capture_output=True, check=True).stdout.decode("latin-1")
+            left = (pathlib.Path(td) / "data.csv").read_bytes()
+        (HERE / out_name).write_text(normalize_driver_output(out), encoding="latin-1")
+        (HERE / (out_name[:-4] + "_csv.sha256")).write_text(hashlib.sha256(left).hexdigest() + f" {len(left)}\n")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "--driver-only" in sys.argv:
+        driver_goldens(HERE / "commands_2k.csv")
+    else:
+        main()

@@ -25,19 +25,26 @@ def normalize(text):
     return text
 
 
-def test_qpehip_prints_what_qpeseq_prints(tmp_path):
+@pytest.mark.parametrize("queries,golden", [("sample-queries.txt", "qpeseq_stdout"), ("sample-queries-FULL.txt", "qpeseq_full_stdout")])
+def test_qpehip_prints_what_qpeseq_prints(tmp_path, queries, golden):
+    """The reference's own query files through both drivers: same stdout, and the same CSV left
+    behind (Sample 5 appends a row; Sample 6 of the FULL file deletes it and rewrites the file
+    without its header, like the reference does)."""
+    import hashlib
     exe = q.PKG / "QPEHIP"
     assert exe.exists(), "build the driver first (make -C parallel-query-processing-system_amd)"
     shutil.copy(q.GOLDEN / "commands_2k.csv", tmp_path / "data.csv")
-    shutil.copy(q.GOLDEN / "sample-queries.txt", tmp_path / "sample-queries.txt")
+    shutil.copy(q.GOLDEN / queries, tmp_path / "sample-queries.txt")         # the driver opens this name (QPESeq.c:40)
     run = subprocess.run([str(exe), "data.csv"], cwd=tmp_path, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode()[-2000:]
     got = normalize(run.stdout.decode("latin-1"))
-    want = (q.GOLDEN / "qpeseq_stdout.txt").read_text(encoding="latin-1")
+    want = (q.GOLDEN / (golden + ".txt")).read_text(encoding="latin-1")
     assert got == want
-    # Sample 5 (INSERT) appended one CSV line, exactly like the reference does
-    lines = (tmp_path / "data.csv").read_bytes().split(b"\n")
-    assert lines[-2].startswith(b"999999,echo 'test insert',echo,bash,0,")
+    left = (tmp_path / "data.csv").read_bytes()
+    sha, size = (q.GOLDEN / (golden + "_csv.sha256")).read_text().split()
+    assert len(left) == int(size) and hashlib.sha256(left).hexdigest() == sha
+    if queries == "sample-queries.txt":
+        assert left.split(b"\n")[-2].startswith(b"999999,echo 'test insert',echo,bash,0,")
 
 
 def test_print_table_text_matches_reference():
