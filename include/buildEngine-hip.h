@@ -43,7 +43,13 @@ struct hipIndex {
     void *keys_dev;          /* n keys, column width                       */
 };
 
-/* Device-resident table; hangs off engineS.record_block. */
+/* Locks of one engine (engine/hip/buildEngine-hip.c).  The OpenMP driver of the reference calls
+ * the engine from several threads at once (QPEOMP.c:234-291); SELECT / COUNT hold `rows` shared and
+ * `device` for their device phase (the context's scratch serves one query at a time), INSERT /
+ * DELETE / index creation hold `rows` exclusively. */
+struct hipLocks;
+
+/* Device-resident table; hangs off engineS.record_block (same address for the engine's life). */
 struct hipTable {
     pqps_ctx *ctx;
     uint64_t n_rows;
@@ -56,7 +62,15 @@ struct hipTable {
     uint64_t *count_dev;                         /* 4 x u64: count, range[2], spare        */
     record *row_block;                           /* contiguous host rows (all_records[i] point in) */
     size_t row_capacity;                         /* rows row_block / all_records have room for      */
+    struct hipLocks *locks;                      /* engine tables only; NULL for ad-hoc tables      */
 };
+
+/* No-ops on a table without locks. */
+void hipTableLockShared(struct hipTable *t);
+void hipTableLockExclusive(struct hipTable *t);
+void hipTableUnlock(struct hipTable *t);
+void hipTableLockDevice(struct hipTable *t);
+void hipTableUnlockDevice(struct hipTable *t);
 
 /* CSV -> contiguous block of records + pointer array (reference signature of
  * getAllRecordsFromFileOMP, buildEngine-omp.h:31). */

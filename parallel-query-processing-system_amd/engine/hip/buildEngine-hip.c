@@ -385,8 +385,19 @@ static void dictionary_free(struct hipDictionary *d) {
     memset(d, 0, sizeof *d);
 }
 
-void hipTableFree(struct hipTable *t, int n_indexes) {
-    if (!t) return;
+struct hipLocks {
+    pthread_rwlock_t rows;
+    pthread_mutex_t device;
+};
+
+void hipTableLockShared(struct hipTable *t) { if (t && t->locks) pthread_rwlock_rdlock(&t->locks->rows); }
+void hipTableLockExclusive(struct hipTable *t) { if (t && t->locks) pthread_rwlock_wrlock(&t->locks->rows); }
+void hipTableUnlock(struct hipTable *t) { if (t && t->locks) pthread_rwlock_unlock(&t->locks->rows); }
+void hipTableLockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_lock(&t->locks->device); }
+void hipTableUnlockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_unlock(&t->locks->device); }
+
+/* Frees what the table owns on the device and its dictionaries, not the struct itself. */
+static void table_release(struct hipTable *t, int n_indexes) {
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         if (t->col[c].data) pqps_free(t->ctx, (void *)t->col[c].data);
         dictionary_free(&t->dict[c]);
@@ -400,6 +411,16 @@ void hipTableFree(struct hipTable *t, int n_indexes) {
     }
     if (t->ids_dev) pqps_free(t->ctx, t->ids_dev);
     if (t->count_dev) pqps_free(t->ctx, t->count_dev);
+}
+
+void hipTableFree(struct hipTable *t, int n_indexes) {
+    if (!t) return;
+    table_release(t, n_indexes);
+    if (t->locks) {
+        pthread_rwlock_destroy(&t->locks->rows);
+        pthread_mutex_destroy(&t->locks->device);
+        free(t->locks);
+    }
     free(t);
 }
 
@@ -447,21 +468,29 @@ bool buildDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
     t->row_block = engine->record_block;               /* block handed over by getAllRecordsFromFileHIP */
     t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 1);
+    t->locks = calloc(1, sizeof *t->locks);
+    if (!t->locks || pthread_rwlock_init(&t->locks->rows, NULL) != 0 || pthread_mutex_init(&t->locks->device, NULL) != 0) {
+        perror("Failed to create engine locks");
+        exit(EXIT_FAILURE);
+    }
     engine->record_block = t;
     return true;
 }
 
 /* Re-creates columns, dictionaries and indexes from the host rows (after INSERT / DELETE). */
 void rebuildDeviceTableHIP(struct engineS *engine) {
-    struct hipTable *old = engine->record_block;
-    pqps_ctx *ctx = old->ctx;
-    record *block = old->row_block;
-    const size_t row_capacity = old->row_capacity;
-    hipTableFree(old, engine->num_indexes);
-    struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
+    struct hipTable *t = engine->record_block;          /* stays at this address: callers hold its locks */
+    pqps_ctx *ctx = t->ctx;
+    record *block = t->row_block;
+    const size_t row_capacity = t->row_capacity;
+    struct hipLocks *locks = t->locks;
+    table_release(t, engine->num_indexes);
+    struct hipTable *fresh = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
+    *t = *fresh;
+    free(fresh);
     t->row_block = block;
     t->row_capacity = row_capacity;
-    engine->record_block = t;
+    t->locks = locks;
     if (engine->num_indexes > 0) {
         t->index = calloc((size_t)engine->num_indexes, sizeof *t->index);
         for (int i = 0; i < engine->num_indexes; i++) build_index(engine, t, i);

@@ -130,29 +130,45 @@ static uint64_t run_selection(struct engineS *engine, struct hipTable *t, struct
     }
 }
 
-long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
-                                   unsigned int **ids, double *queryTime) {
-    if (!engine || !engine->record_block || !ids) return -1;
+/* Caller holds the rows lock (shared).  The device phase -- the context's scratch and the table's
+ * result buffer serve one query at a time -- runs under the device lock. */
+static long long select_ids(struct engineS *engine, struct whereClauseS *whereClause,
+                            unsigned int **ids, double *queryTime) {
     struct hipTable *t = engine->record_block;
     const double t0 = now_seconds();
+    hipTableLockDevice(t);
     const uint64_t count = run_selection(engine, t, whereClause);
     unsigned int *out = malloc((count ? count : 1) * sizeof *out);
     if (!out) { perror("Failed to allocate memory for result IDs"); exit(EXIT_FAILURE); }
     if (count) SHIM(pqps_download(t->ctx, out, t->ids_dev, count * sizeof *out, NULL), "ID download");
+    hipTableUnlockDevice(t);
     if (queryTime) *queryTime = now_seconds() - t0;
     *ids = out;
     return (long long)count;
 }
 
+long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
+                                   unsigned int **ids, double *queryTime) {
+    if (!engine || !engine->record_block || !ids) return -1;
+    hipTableLockShared(engine->record_block);
+    const long long count = select_ids(engine, whereClause, ids, queryTime);
+    hipTableUnlock(engine->record_block);
+    return count;
+}
+
 long long executeQueryCountHIP(struct engineS *engine, struct whereClauseS *whereClause) {
     if (!engine || !engine->record_block) return -1;
     struct hipTable *t = engine->record_block;
+    hipTableLockShared(t);
     struct bound_pred bp;
     bind_where(t, whereClause, &bp);
+    hipTableLockDevice(t);
     SHIM(pqps_filter_count(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, t->count_dev, NULL), "count filter");
     SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
     uint64_t count = 0;
     SHIM(pqps_download(t->ctx, &count, t->count_dev, sizeof count, NULL), "count download");
+    hipTableUnlockDevice(t);
+    hipTableUnlock(t);
     return (long long)count;
 }
 
@@ -204,8 +220,9 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
 
     unsigned int *ids = NULL;
     double qtime = 0.0;
-    const long long count = executeQuerySelectIdsHIP(engine, whereClause, &ids, &qtime);
-    if (count < 0) { rs->success = false; return rs; }
+    if (!engine || !engine->record_block) { rs->success = false; return rs; }
+    hipTableLockShared(engine->record_block);          /* the projection below reads the host rows */
+    const long long count = select_ids(engine, whereClause, &ids, &qtime);
 
     rs->numRecords = (int)count;
     if (selectItems == NULL || numSelectItems == 0) {  /* SELECT *, S:490-492 */
@@ -237,6 +254,7 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
         if (nt == 1 || pthread_create(&tid[k], NULL, project_rows, &job[k]) != 0) { project_rows(&job[k]); tid[k] = 0; }
     }
     for (int k = 0; k < nt; k++) if (nt > 1 && tid[k]) pthread_join(tid[k], NULL);
+    hipTableUnlock(engine->record_block);
     free(cols);
     free(ids);
     rs->columnTypes = calloc((size_t)rs->numColumns, sizeof(FieldType));   /* placeholder, S:524-525 */
@@ -273,6 +291,7 @@ int isAttributeIndexed(struct engineS *engine, const char *attributeName) {
 /* ---- helpers over caller-supplied rows ---------------------------------------------- */
 
 static pqps_ctx *g_adhoc_ctx;
+static pthread_mutex_t g_adhoc_lock = PTHREAD_MUTEX_INITIALIZER;   /* one shared context: one ad-hoc filter at a time */
 
 static pqps_ctx *adhoc_ctx(void) {
     if (!g_adhoc_ctx) {
@@ -289,6 +308,7 @@ static pqps_ctx *adhoc_ctx(void) {
 record **linearSearchRecords(record **records, int num_records, struct whereClauseS *whereClause,
                              int *matchingRecords) {
     *matchingRecords = 0;
+    pthread_mutex_lock(&g_adhoc_lock);
     struct hipTable *t = hipTableFromRows(adhoc_ctx(), records, (size_t)(num_records > 0 ? num_records : 0));
     struct bound_pred bp;
     bind_where(t, whereClause, &bp);
@@ -304,6 +324,7 @@ record **linearSearchRecords(record **records, int num_records, struct whereClau
     for (uint64_t i = 0; i < count; i++) out[i] = records[ids[i]];
     free(ids);
     hipTableFree(t, 0);
+    pthread_mutex_unlock(&g_adhoc_lock);
     *matchingRecords = (int)count;
     return out;
 }
@@ -356,7 +377,10 @@ void destroyEngineHIP(struct engineS *engine) {
 bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const char *attributeName,
                           int attributeType) {
     (void)tableName;
-    return makeIndexHIP(engine, attributeName, attributeType);
+    hipTableLockExclusive(engine->record_block);
+    const bool ok = makeIndexHIP(engine, attributeName, attributeType);
+    hipTableUnlock(engine->record_block);
+    return ok;
 }
 
 /* ---- mutation (kept in step with the CSV like the reference) ------------------------------ */
@@ -373,19 +397,20 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     if (r->command_id == 0 || !r->raw_command[0] || !r->base_command[0] || !r->shell_type[0] ||
         !r->timestamp[0] || !r->working_directory[0] || !r->user_name[0] || !r->host_name[0])
         return false;                                              /* S:544-551 */
+    struct hipTable *t = engine->record_block;
+    hipTableLockExclusive(t);
     FILE *f = fopen(engine->datafile, "a");
-    if (!f) return false;
+    if (!f) { hipTableUnlock(t); return false; }
     write_csv_row(f, r);
     fclose(f);
 
-    struct hipTable *t = engine->record_block;
     const size_t n = (size_t)engine->num_records;
     /* host row store grows geometrically; all_records[] is re-pointed only when the block moved */
     if (n + 1 > t->row_capacity) {
         const size_t cap = n + n / 8 + 64;
         record *block = realloc(t->row_block, cap * sizeof *block);
         record **rows = realloc(engine->all_records, cap * sizeof *rows);
-        if (!block || !rows) return false;
+        if (!block || !rows) { hipTableUnlock(t); return false; }
         if (block != t->row_block) for (size_t i = 0; i < n; i++) rows[i] = &block[i];
         t->row_block = block;
         t->row_capacity = cap;
@@ -395,6 +420,7 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     engine->all_records[n] = &t->row_block[n];
     engine->num_records = (int)(n + 1);
     appendRowDeviceTableHIP(engine);
+    hipTableUnlock(t);
     return true;
 }
 
@@ -407,6 +433,7 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
     const double t0 = now_seconds();
     struct hipTable *t = engine->record_block;
+    hipTableLockExclusive(t);
     const size_t n = (size_t)engine->num_records;
     struct bound_pred bp;
     bind_where(t, whereClause, &bp);
@@ -436,6 +463,7 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
      * stay as they are (a code without rows is harmless), indexes are re-sorted */
     if (deleted) compactDeviceTableHIP(engine, flags_dev, keep);
     pqps_free(t->ctx, flags_dev);
+    hipTableUnlock(t);
     rs->numRecords = (int)deleted;
     rs->queryTime = now_seconds() - t0;
     rs->success = true;

@@ -141,6 +141,71 @@ def test_insert_then_delete_roundtrip(tmp_path):
     eng.close()
 
 
+def test_engine_is_safe_under_concurrent_callers(tmp_path):
+    """The reference's OpenMP driver calls one engine from several threads (QPEOMP.c:234-291).
+    8 reader threads (scan mode, index mode, COUNT, projection) run against a writer that keeps
+    INSERTing and DELETEing a row no reader's predicate matches: every answer must equal the
+    single-threaded one."""
+    import threading
+    csv = tmp_path / "data.csv"
+    shutil.copy(q.GOLDEN / "commands_2k.csv", csv)
+    L = pq.lib()
+    eng = pq.HipEngine(csv, pq.DEFAULT_INDEXES)
+    n0 = eng.n
+    chains = [[("risk_level", ">=", "4")], [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")],
+              [("user_name", "=", "student1030"), "OR", ("shell_type", "=", "fish")],
+              [("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1100")], [("command_id", "<", "100")],
+              [("risk_level", ">=", "4"), "AND", ("exit_code", "=", "0")]]
+    want_ids = [eng.select_ids(c) for c in chains]
+    want_cnt = [eng.count(c) for c in chains]
+    want_rows = [eng.select(["command_id", "user_name", "raw_command"], c)["rows"] for c in chains]
+    errors, stop = [], threading.Event()
+
+    def reader(k):
+        try:
+            for it in range(40):
+                i = (k + it) % len(chains)
+                if eng.select_ids(chains[i]) != want_ids[i]:
+                    errors.append(("ids", k, i))
+                if eng.count(chains[i]) != want_cnt[i]:
+                    errors.append(("count", k, i))
+                if it % 4 == 0 and eng.select(["command_id", "user_name", "raw_command"], chains[i])["rows"] != want_rows[i]:
+                    errors.append(("rows", k, i))
+        except Exception as e:                                      # noqa: BLE001
+            errors.append(("exception", k, repr(e)))
+
+    def writer():
+        r = pq.Record()
+        r.command_id, r.exit_code, r.user_id, r.risk_level, r.sudo_used = 999999, 0, 1000, 1, False
+        r.raw_command, r.base_command, r.shell_type = b"echo x", b"echo", b"bash"
+        r.timestamp, r.working_directory, r.user_name, r.host_name = b"2025-12-01T12:00:00.000Z", b"/tmp", b"zz_writer", b"zz-host"
+        wl = pq.WhereList([("command_id", "=", "999999")])
+        try:
+            while not stop.is_set():
+                if not L.executeQueryInsertHIP(eng.e, b"Commands", C.byref(r)):
+                    errors.append(("insert failed",))
+                rs = L.executeQueryDeleteHIP(eng.e, b"Commands", wl.ptr)
+                if rs.contents.numRecords != 1:
+                    errors.append(("delete count", rs.contents.numRecords))
+                L.freeResultSet(rs)
+        except Exception as e:                                      # noqa: BLE001
+            errors.append(("writer exception", repr(e)))
+
+    threads = [threading.Thread(target=reader, args=(k,)) for k in range(8)]
+    w = threading.Thread(target=writer)
+    w.start()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    stop.set()
+    w.join()
+    assert not errors, errors[:5]
+    assert eng.e.contents.num_records == n0
+    assert [eng.select_ids(c) for c in chains] == want_ids
+    eng.close()
+
+
 def test_engine_fails_loudly_without_a_device(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); import qpelib as q; "
             "q.pq.HipEngine(%r, [])" % (str(q.ROOT / "tests"), str(q.GOLDEN / "commands_2k.csv")))
