@@ -28,6 +28,14 @@ static double now_seconds(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* PQPS_TRACE=1: phase timings of every engine call on stderr. */
+static int trace_on(void) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("PQPS_TRACE"); on = e && atoi(e) != 0; }
+    return on;
+}
+#define TRACE(...) do { if (trace_on()) fprintf(stderr, "[pqps] " __VA_ARGS__); } while (0)
+
 static void engine_die(const char *what) {
     fprintf(stderr, "HIP engine: %s: %s\n", what, pqps_last_error());
     exit(EXIT_FAILURE);
@@ -240,6 +248,7 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
     rs->data = malloc((count ? (size_t)count : 1) * sizeof(char **));
 
     /* S:504-515 -- rows x columns heap strings, the result-set contract of the reference */
+    const double t_proj = now_seconds();
     int nt = 1;
     if (count >= 8192) {
         const char *env = getenv("PQPS_HOST_THREADS");
@@ -255,6 +264,8 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
     }
     for (int k = 0; k < nt; k++) if (nt > 1 && tid[k]) pthread_join(tid[k], NULL);
     hipTableUnlock(engine->record_block);
+    TRACE("SELECT: %lld rows x %d columns, selection %.3f ms, projection %.3f ms (%d threads)\n", count, rs->numColumns,
+          qtime * 1e3, (now_seconds() - t_proj) * 1e3, nt);
     free(cols);
     free(ids);
     rs->columnTypes = calloc((size_t)rs->numColumns, sizeof(FieldType));   /* placeholder, S:524-525 */
@@ -392,12 +403,93 @@ static void write_csv_row(FILE *f, const record *r) {           /* S:562, S:687 
 }
 
 /* executeQueryInsertSerial, S:538-617. */
+/* The whole table as CSV text, rows formatted exactly like write_csv_row (S:687-700), by host
+ * threads into per-range buffers that are then written in order: the rewrite after a DELETE is
+ * the reference's own file format and by far the longest phase of a DELETE on a large table. */
+struct csv_job { const record *rows; size_t begin, end; char *buf; size_t len; };
+
+static char *put_u64(char *p, unsigned long long v) {
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *p++ = tmp[--k];
+    return p;
+}
+
+static char *put_i32(char *p, int v) {
+    unsigned long long u = v < 0 ? (unsigned long long)(-(long long)v) : (unsigned long long)v;
+    if (v < 0) *p++ = '-';
+    return put_u64(p, u);
+}
+
+static char *put_str(char *p, const char *s) {
+    const size_t k = strlen(s);
+    memcpy(p, s, k);
+    return p + k;
+}
+
+static void *csv_format_rows(void *arg) {
+    struct csv_job *j = arg;
+    /* exact room: the strings as "%s" would print them (a field filled to its last byte has no NUL
+     * and runs on into the next one, in the reference's fprintf as well) + 5 numbers + separators */
+    size_t room = 1;
+    for (size_t i = j->begin; i < j->end; i++) {
+        const record *r = &j->rows[i];
+        room += strlen(r->raw_command) + strlen(r->base_command) + strlen(r->shell_type) + strlen(r->timestamp) +
+                strlen(r->working_directory) + strlen(r->user_name) + strlen(r->host_name) + 5 * 21 + 12;
+    }
+    j->buf = malloc(room);
+    if (!j->buf) { j->len = 0; return NULL; }
+    char *p = j->buf;
+    for (size_t i = j->begin; i < j->end; i++) {
+        const record *r = &j->rows[i];
+        p = put_u64(p, r->command_id); *p++ = ',';
+        p = put_str(p, r->raw_command); *p++ = ',';
+        p = put_str(p, r->base_command); *p++ = ',';
+        p = put_str(p, r->shell_type); *p++ = ',';
+        p = put_i32(p, r->exit_code); *p++ = ',';
+        p = put_str(p, r->timestamp); *p++ = ',';
+        p = put_i32(p, (int)r->sudo_used); *p++ = ',';
+        p = put_str(p, r->working_directory); *p++ = ',';
+        p = put_i32(p, r->user_id); *p++ = ',';
+        p = put_str(p, r->user_name); *p++ = ',';
+        p = put_str(p, r->host_name); *p++ = ',';
+        p = put_i32(p, r->risk_level); *p++ = '\n';
+    }
+    j->len = (size_t)(p - j->buf);
+    return NULL;
+}
+
+static void write_csv_table(FILE *f, const record *rows, size_t n) {
+    enum { kMaxJobs = 16, kChunkRows = 65536 };
+    for (size_t base = 0; base < n; ) {                         /* bounded memory: <= 16 chunks in flight */
+        struct csv_job job[kMaxJobs];
+        pthread_t tid[kMaxJobs];
+        int nj = 0;
+        while (nj < kMaxJobs && base < n) {
+            const size_t end = base + kChunkRows < n ? base + kChunkRows : n;
+            job[nj] = (struct csv_job){ rows, base, end, NULL, 0 };
+            base = end;
+            nj++;
+        }
+        for (int k = 0; k < nj; k++)
+            if (nj == 1 || pthread_create(&tid[k], NULL, csv_format_rows, &job[k]) != 0) { csv_format_rows(&job[k]); tid[k] = 0; }
+        for (int k = 0; k < nj; k++) {
+            if (nj > 1 && tid[k]) pthread_join(tid[k], NULL);
+            if (job[k].buf) fwrite(job[k].buf, 1, job[k].len, f);
+            else for (size_t i = job[k].begin; i < job[k].end; i++) write_csv_row(f, &rows[i]);   /* out of memory: plain path */
+            free(job[k].buf);
+        }
+    }
+}
+
 bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const record *r) {
     (void)tableName;
     if (r->command_id == 0 || !r->raw_command[0] || !r->base_command[0] || !r->shell_type[0] ||
         !r->timestamp[0] || !r->working_directory[0] || !r->user_name[0] || !r->host_name[0])
         return false;                                              /* S:544-551 */
     struct hipTable *t = engine->record_block;
+    const double t0 = now_seconds();
     hipTableLockExclusive(t);
     FILE *f = fopen(engine->datafile, "a");
     if (!f) { hipTableUnlock(t); return false; }
@@ -419,7 +511,9 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     t->row_block[n] = *r;
     engine->all_records[n] = &t->row_block[n];
     engine->num_records = (int)(n + 1);
+    const double t1 = now_seconds();
     appendRowDeviceTableHIP(engine);
+    TRACE("INSERT: CSV append + host row %.3f ms, device append + indexes %.3f ms\n", (t1 - t0) * 1e3, (now_seconds() - t1) * 1e3);
     hipTableUnlock(t);
     return true;
 }
@@ -442,6 +536,7 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     SHIM(pqps_filter_flags(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, flags_dev, t->count_dev, NULL), "flag filter");
     SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
     if (n) SHIM(pqps_download(t->ctx, flags, flags_dev, n, NULL), "flag download");
+    const double t1 = now_seconds();
 
     size_t keep = 0, deleted = 0;
     record *block = t->row_block;
@@ -453,16 +548,20 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     free(flags);
     for (size_t i = 0; i < keep; i++) engine->all_records[i] = &block[i];
     engine->num_records = (int)keep;
+    const double t2 = now_seconds();
 
     FILE *f = fopen(engine->datafile, "w");                       /* S:683-701: no header written */
     if (f) {
-        for (size_t i = 0; i < keep; i++) write_csv_row(f, &block[i]);
+        write_csv_table(f, block, keep);
         fclose(f);
     }
+    const double t3 = now_seconds();
     /* device side: the same flags compact the 12 columns in place (order kept); dictionaries
      * stay as they are (a code without rows is harmless), indexes are re-sorted */
     if (deleted) compactDeviceTableHIP(engine, flags_dev, keep);
     pqps_free(t->ctx, flags_dev);
+    TRACE("DELETE: %zu of %zu rows, flags %.3f ms, host rows %.3f ms, CSV rewrite %.3f ms, device compaction + indexes %.3f ms\n",
+          deleted, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now_seconds() - t3) * 1e3);
     hipTableUnlock(t);
     rs->numRecords = (int)deleted;
     rs->queryTime = now_seconds() - t0;

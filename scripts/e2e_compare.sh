@@ -12,5 +12,6 @@ echo "== QPEHIP"; ( time $GRAFT_REPO_ROOT/parallel-query-processing-system_amd/Q
 norm() { sed -E 's/Query Time: [0-9.]+ seconds/Query Time: X seconds/; s/Execution Time: [0-9.]+/Execution Time: X/' "$1" | sed '/Execution Summary/,$d'; }
 norm ref.out > ref.norm; norm hip.out > hip.norm
 if cmp -s ref.norm hip.norm; then echo "OUTPUT IDENTICAL ($(wc -l < ref.norm) lines)"; else echo "OUTPUT DIFFERS"; diff ref.norm hip.norm | head -20; fi
+if cmp -s data_ref.csv data_hip.csv; then echo "CSV LEFT BEHIND IDENTICAL ($(wc -c < data_ref.csv) bytes)"; else echo "CSV LEFT BEHIND DIFFERS"; fi
 grep -a "Query Time" ref.out | head -8; echo --; grep -a "Query Time" hip.out | head -8
 rm -rf $work
