@@ -322,7 +322,7 @@ def main():
                    "query": sql, "rows_per_gpu": args.rows, "rows_total": n_global,
                    "matches_total": total_matches, "selectivity": total_matches / n_global,
                    "bytes_per_row": bytes_per_row,
-                   "parallelism": f"row-range shards x{world}" + (f", one RCCL [count|IDs] all-gather + device merge per query on every rank ({'shim-driven' if native else 'torch.distributed'})" if exchange else ""),
+                   "parallelism": f"row-range shards x{world}" + (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} [count|IDs] all-gather + device merge per query on every rank ({'shim-driven' if native else 'torch.distributed'})" if exchange else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
