@@ -583,3 +583,40 @@ def test_full_size_properties(ctx):
         ctx.free(flags_dev)
         out.free()
         dev.free()
+
+
+def test_row_ids_above_two_to_the_31(ctx):
+    """4 000 000 001 rows on one GPU (the shim's row IDs are u32; the reference's int counts stop at
+    2^31-1): the last partial step, the streaming-load kernel variant, one group per wave in K3 and
+    every 64-bit offset.  The head (first 2 M rows) and the tail (last 2 M rows, IDs ~ 4e9) of
+    the ID list are bit-exact against the host twin, the middle by COUNT(*) and order."""
+    n = 4_000_000_001
+    seed = 77
+    dev = pq.SyntheticTable(ctx, n, seed=seed, columns=["sudo_used", "user_name"])
+    chain = QUERIES["S1"]
+    out = DeviceOut(ctx, 1 << 20)
+    try:
+        ids = gpu_scan(ctx, dev, chain, out)
+        k = len(ids)
+        assert 100_000 < k < out.cap
+        assert np.all(ids[1:] > ids[:-1])
+        assert int(ids[-1]) > 2**31 and int(ids[-1]) < n
+        assert gpu_count(ctx, dev, chain, out) == k
+        m = 2_000_000
+        head = q.HostSynth(m, seed=seed).oracle_scan(chain)
+        assert np.array_equal(ids[:len(head)], head) and ids[len(head)] >= m
+        tail = q.HostSynth(m, seed=seed, row0=n - m).oracle_scan(chain, id_base=n - m)
+        assert len(tail) > 0 and np.array_equal(ids[k - len(tail):], tail.astype(np.uint32))
+        assert ids[k - len(tail) - 1] < n - m
+        # a dense answer near the top of the ID space, through the index-free gather of a shard
+        start = n - 3_000_000
+        shard = pq.SyntheticTable(ctx, 3_000_000, seed=seed, row0=start, columns=["sudo_used", "user_name"])
+        out2 = DeviceOut(ctx, 3_000_000)
+        got = gpu_scan(ctx, shard, [("sudo_used", "=", "FALSE")], out2, id_base=start)
+        want = q.HostSynth(3_000_000, seed=seed, row0=start).oracle_scan([("sudo_used", "=", "FALSE")], id_base=start)
+        assert np.array_equal(got, want.astype(np.uint32)) and int(got[-1]) > 2**31
+        out2.free()
+        shard.free()
+    finally:
+        out.free()
+        dev.free()
