@@ -53,6 +53,8 @@ struct EvalArgs {
     uint32_t n_cols;
     uint32_t n_leaves;
     uint32_t negmask;
+    uint32_t streaming;              // host side only: the scan outgrows the Infinity Cache (grid + load policy)
+    uint32_t steps_per_iter;         // host side only: S of the chosen kernel (grid sizing)
     uint32_t chain;                  // 0: general tree; 1: AND of leaves; 2: NOT(AND) = OR form (spec kernels)
     uint32_t chain_want;             // bit k: raw window hit that leaf slot k must have inside the AND
     uint32_t pad0;
@@ -322,7 +324,11 @@ __device__ __forceinline__ void emit_planes(const EvalArgs &a, uint64_t step, Ro
     }
 }
 
-// COUNT / FLAGS modes: one partial total per workgroup, summed by reduce_totals_kernel.
+// COUNT / FLAGS modes: every workgroup adds its total into one of kPartialSlots counters (the grid
+// can be far larger than that; spread over 4096 addresses the atomics do not queue up), which
+// reduce_totals_kernel sums and leaves zeroed for the next query.
+constexpr uint32_t kPartialSlots = 4096;
+
 template <int MODE>
 __device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_total) {
     if (MODE == MODE_IDS) return;
@@ -332,7 +338,7 @@ __device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_t
     if (threadIdx.x == 0) {
         uint64_t t = 0;
         for (int i = 0; i < kWaves; i++) t += s_tot[i];
-        a.partials[blockIdx.x] = t;
+        if (t) atomicAdd((unsigned long long *)&a.partials[blockIdx.x & (kPartialSlots - 1)], (unsigned long long)t);
     }
 }
 
@@ -726,10 +732,13 @@ __global__ __launch_bounds__(kBlock) void group_sum_kernel(const SumArgs a) {
 }
 
 // COUNT / FLAGS modes: workgroup partial totals -> one number (no same-address atomics)
-__global__ __launch_bounds__(kBlock) void reduce_totals_kernel(const uint64_t *partials, uint32_t n, uint64_t *out_count) {
+__global__ __launch_bounds__(kBlock) void reduce_totals_kernel(uint64_t *partials, uint64_t *out_count) {
     __shared__ uint64_t s_wave[kWaves];
     uint64_t local = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) local += partials[i];
+    for (uint32_t i = threadIdx.x; i < kPartialSlots; i += kBlock) {
+        const uint64_t v = partials[i];
+        if (v) { local += v; partials[i] = 0; }                 // left zeroed for the next query
+    }
     local = wave_sum_u64(local);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = local;
     __syncthreads();

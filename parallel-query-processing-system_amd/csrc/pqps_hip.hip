@@ -220,7 +220,7 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 constexpr int kMaxTimedLaunches = 4096;
-constexpr int kEvalBlocksPerCU = 16;     // grid cap of K1 (grid-stride beyond it)
+constexpr int kEvalBlocksPerCUMax = 1024; // grid cap of K1 per CU (grid-stride beyond it)
 
 struct pqps_ctx {
     int device;
@@ -269,7 +269,8 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     HIP_TRY(hipMalloc((void **)&ctx->group_sum, groups * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->super_sum, supers * kSuperStride * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&ctx->base_slot, 64));
-    HIP_TRY(hipMalloc((void **)&ctx->partials, (size_t)ctx->compute_units * kEvalBlocksPerCU * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->partials, kPartialSlots * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(ctx->partials, 0, kPartialSlots * sizeof(uint64_t)));
     ctx->scratch_steps = cap;
     return PQPS_OK;
 }
@@ -364,33 +365,63 @@ eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool mul
     return nullptr;
 }
 
-// Streaming (`nt`) loads once the columns read by the query outgrow the Infinity Cache (256 MB on
-// MI355X) by a margin; below that a repeated scan finds part of the table cached and plain loads win.
+// A scan is "streaming" once the columns it reads outgrow the Infinity Cache (256 MB on MI355X) by
+// a margin: it then uses `nt` loads and a one-shot grid; below that a repeated scan finds part of
+// the table cached and plain loads win.
 constexpr uint64_t kStreamingFootprint = 320ull << 20;
 
-template <int MODE>
-eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, uint64_t footprint) {
+bool is_streaming(uint64_t footprint) {
     static const char *force = getenv("PQPS_NT_LOADS");
-    const bool nt = force ? atoi(force) != 0 : footprint > kStreamingFootprint;
+    return force ? atoi(force) != 0 : footprint > kStreamingFootprint;
+}
+
+void set_streaming(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows) {
+    uint64_t row_bytes = 0;
+    for (uint32_t c = 0; c < n_cols; c++) row_bytes += cols[c].width;
+    a.streaming = is_streaming(n_rows * row_bytes) ? 1u : 0u;
+}
+
+template <int MODE>
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool nt) {
     return nt ? find_spec_nt<MODE, true>(w0, w1, w2, chain, multi_step) : find_spec_nt<MODE, false>(w0, w1, w2, chain, multi_step);
 }
 
-// `a` must already carry the chain classification of fill_args().
+// `a` must already carry the chain classification of fill_args(); sets a.streaming.
 template <int MODE>
-eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred, const EvalArgs &a, uint64_t n_rows) {
+eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred, EvalArgs &a, uint64_t n_rows) {
+    set_streaming(a, cols, n_cols, n_rows);
     if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1 && pred->n_leaves <= PQPS_TT_LEAVES) {
         const uint32_t w0 = cols[0].width, w1 = n_cols > 1 ? cols[1].width : 0, w2 = n_cols > 2 ? cols[2].width : 0;
         // several steps per iteration only where chain_steps() says so (a lone 1-byte column)
         static const char *force = getenv("PQPS_CHAIN_MULTI");
         const bool multi = force ? atoi(force) != 0 : true;
-        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, n_rows * (w0 + w1 + w2))) return f;   // nullptr unless widths are non-increasing
+        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, a.streaming != 0)) {   // nullptr unless widths are non-increasing
+            if (a.chain != 0 && multi) a.steps_per_iter = (uint32_t)chain_steps((int)w0, (int)w1, (int)w2);
+            return f;
+        }
     }
     return eval_generic_kernel<MODE, false>;
 }
 
-uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps) {
-    const uint64_t want = (steps + kWaves - 1) / kWaves;
-    const uint64_t cap = (uint64_t)ctx->compute_units * kEvalBlocksPerCU;
+// Workgroups of K1.  Measured (fraction of 8 TB/s, S1 / Q_A / Q_C at 0.1 - 1 G rows): waves that
+// grid-stride through many iterations drift apart and the chip-wide access window loses its
+// locality -- 60 iterations per wave 0.72, 15 -> 0.77, 4 -> 0.82, 1 -> 0.84 at 1 G rows.  So a
+// streaming scan is launched one-shot (a workgroup = 4 consecutive steps, dealt out in address order
+// by the dispatcher; the grid-stride loop only engages beyond 1024 workgroups per CU), while a scan
+// small enough to find part of its columns in the Infinity Cache does best with ~1.5 iterations
+// (0.82 against 0.78 one-shot at 100 M rows x 3 B).
+uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps, bool streaming, uint32_t steps_per_iter) {
+    const uint64_t per_wg = (uint64_t)kWaves * (steps_per_iter ? steps_per_iter : 1);   // steps one workgroup takes per iteration
+    const uint64_t want = (steps + per_wg - 1) / per_wg;
+    uint64_t cap = streaming ? (uint64_t)ctx->compute_units * kEvalBlocksPerCUMax : want * 2 / 3 + 1;
+    static const char *env = getenv("PQPS_K1_BLOCKS_PER_CU");    // tuning runs
+    if (env && atoi(env) >= 1 && atoi(env) <= kEvalBlocksPerCUMax) cap = (uint64_t)ctx->compute_units * (uint64_t)atoi(env);
+    static const char *it_env = getenv("PQPS_K1_ITERS");          // tuning runs: iterations per wave
+    if (it_env && atof(it_env) > 0) {
+        cap = (uint64_t)((double)want / atof(it_env)) + 1;
+        const uint64_t hard = (uint64_t)ctx->compute_units * kEvalBlocksPerCUMax;
+        if (cap > hard) cap = hard;
+    }
     const uint64_t g = want < cap ? want : cap;
     return (uint32_t)(g ? g : 1);
 }
@@ -411,7 +442,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.partials = ctx->partials;
     a.super_sum = ctx->super_sum;
     a.n_super = (uint32_t)((groups + kSuperGroups - 1) / kSuperGroups);
-    const uint32_t grid = eval_grid(ctx, steps);
+    const uint32_t grid = eval_grid(ctx, steps, a.streaming != 0, a.steps_per_iter);
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
     if (timed) {
         // the two events are attached to the dispatch itself: they carry the kernel's own begin /
@@ -422,8 +453,8 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     }
     HIP_TRY(hipGetLastError());
     if (mode != MODE_IDS) {
-        if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, grid, out_count);
-        else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, out_count);
+        if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, out_count);
+        else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, out_count);
         HIP_TRY(hipGetLastError());
     } else {
         SumArgs sa;
