@@ -443,7 +443,8 @@ __device__ __forceinline__ uint32_t eval_step_guarded(const EvalArgs &a, uint64_
 }
 
 // Generic K1: any predicate; scan (full steps vectorised) or gather (always guarded).
-// K2 accumulates supergroup sums with atomics; the first workgroup of K1 clears them.
+// K2 accumulates supergroup sums with atomics; the first workgroup of K1 clears them -- at its END,
+// so that no workgroup starts with a kernel-argument round trip for something only K2 needs.
 template <int MODE>
 __device__ __forceinline__ void clear_super_sums(const EvalArgs &a) {
     if (MODE == MODE_IDS && blockIdx.x == 0)
@@ -452,7 +453,6 @@ __device__ __forceinline__ void clear_super_sums(const EvalArgs &a) {
 
 template <int MODE, bool GATHER>
 __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) {
-    clear_super_sums<MODE>(a);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) 
         else if (step_row0 < n_rows) mbits = eval_step_guarded<GATHER>(a, step_row0, n_rows, begin, lane);
         emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
     }
+    clear_super_sums<MODE>(a);
     finish_totals<MODE>(a, wave_total);
 }
 
@@ -615,6 +616,15 @@ struct RawStep {
 };
 
 // W0 >= W1 >= W2 are the byte widths of the predicate columns (0 = slot unused).
+// The kernel arguments the first loads depend on, fetched together at the very top: left to itself the
+// compiler fetches them where first used, three dependent scalar-load round trips (~0.6 us) before a
+// wave has a byte of the table in flight -- which a one-shot workgroup pays on every launch.
+#define PQPS_HOIST_KERNARGS(a)                                                                        \
+    asm volatile("" :: "s"((a).n_rows), "s"((a).col[0]), "s"((a).col[1]), "s"((a).col[2]), "s"(gridDim.x),  \
+                 "s"((a).masks), "s"((a).counts), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask),     \
+                 "s"((uint32_t)(a).leaf_begin[0]), "s"((uint32_t)(a).leaf_begin[1]), "s"((uint32_t)(a).leaf_begin[2]), \
+                 "s"((uint32_t)(a).leaf_begin[3]))
+
 // General tree of <= 6 leaves (row-mask path), one step per iteration.
 template <int MODE, int W0, int W1, int W2, bool NT>
 __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
@@ -622,11 +632,11 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;                                 // chunks per step
-    clear_super_sums<MODE>(a);
+    PQPS_HOIST_KERNARGS(a);
+    const uint64_t n_rows = a.n_rows;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
-    const uint64_t n_rows = a.n_rows;
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
     uint64_t wave_total = 0;
@@ -640,6 +650,7 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
         const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
         emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
     }
+    clear_super_sums<MODE>(a);
     finish_totals<MODE>(a, wave_total);
 }
 
@@ -655,11 +666,11 @@ template <int MODE, int W0, int W1, int W2, int S, bool NT>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
-    clear_super_sums<MODE>(a);
+    PQPS_HOIST_KERNARGS(a);
+    const uint64_t n_rows = a.n_rows;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
-    const uint64_t n_rows = a.n_rows;
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
     uint64_t wave_total = 0;
@@ -683,6 +694,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
         const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
         emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
     }
+    clear_super_sums<MODE>(a);
     finish_totals<MODE>(a, wave_total);
 }
 
