@@ -257,70 +257,70 @@ __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint
 // Every leaf-row compare writes its 64-lane result straight into an SGPR pair (one VALU, SDWA
 // picks the byte / halfword); AND-ing the leaves and counting the matches is scalar-unit work;
 // per-lane match bits are only materialised for steps that contain a match.
-struct RowPlanes { uint64_t p[16]; };                           // p[r] bit l = row r of lane l
+// A step is evaluated in two halves of 8 row slots: 8 planes (16 SGPRs) live at a time instead of 16,
+// which is what brings the kernel under 96 SGPRs, i.e. to 8 waves per SIMD instead of 7.
+struct RowPlanes { uint64_t p[8]; };                            // half H: p[i] bit l = row slot 8H + i of lane l
 
-template <typename T>
+template <typename T, int H>
 __device__ __forceinline__ void chain_leaf(const T (&v)[16], T lo, T span, bool want, RowPlanes &acc) {
     // `want`: the raw window hit this leaf needs; the four branches are wave-uniform
     if (span == 0) {
         if (want) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] == lo);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot(v[8 * H + r] == lo);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] != lo);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot(v[8 * H + r] != lo);
         }
     } else if (lo == 0) {
         if (want) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] <= span);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot(v[8 * H + r] <= span);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot(v[r] > span);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot(v[8 * H + r] > span);
         }
     } else {
         if (want) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot((T)(v[r] - lo) <= span);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot((T)(v[8 * H + r] - lo) <= span);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc.p[r] &= __ballot((T)(v[r] - lo) > span);
+            for (int r = 0; r < 8; r++) acc.p[r] &= __ballot((T)(v[8 * H + r] - lo) > span);
+        }
+    }
+}
+
+// Folds one evaluated half into the step's match count and (ID output, only if the half has a match)
+// into the lanes' match-bit words.
+template <int MODE, int H>
+__device__ __forceinline__ void fold_half(const EvalArgs &a, RowPlanes &acc, uint32_t &cnt, uint32_t &mbits) {
+    if (a.chain == 2) {                                         // OR form: NOT of the AND
+#pragma unroll
+        for (int r = 0; r < 8; r++) acc.p[r] = ~acc.p[r];
+    }
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) any |= acc.p[r];
+    if (any) {                                                  // uniform
+#pragma unroll
+        for (int r = 0; r < 8; r++) cnt += (uint32_t)__popcll(acc.p[r]);
+        if (MODE == MODE_IDS) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) mbits |= __builtin_amdgcn_inverse_ballot_w64(acc.p[r]) ? (1u << (8 * H + r)) : 0u;
         }
     }
 }
 
 template <int MODE>
-__device__ __forceinline__ void emit_planes(const EvalArgs &a, uint64_t step, RowPlanes &acc, uint32_t rpl_log2,
-                                            uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
-    if (a.chain == 2) {                                         // OR form: NOT of the AND
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc.p[r] = ~acc.p[r];
-    }
-    uint64_t any = 0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) any |= acc.p[r];
-    uint32_t cnt = 0;
-    if (any) {                                                  // uniform
-#pragma unroll
-        for (int r = 0; r < 16; r++) cnt += (uint32_t)__popcll(acc.p[r]);
-    }
+__device__ __forceinline__ void emit_chain_step(const EvalArgs &a, uint64_t step, uint32_t cnt, uint32_t mbits,
+                                                uint32_t rpl_log2, uint32_t lane, uint64_t &wave_total) {
+    static_assert(MODE != MODE_FLAGS, "flag output goes through the generic kernel");
     if (MODE == MODE_IDS) {
-        if (cnt) {
-            uint32_t mbits = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) mbits |= __builtin_amdgcn_inverse_ballot_w64(acc.p[r]) ? (1u << r) : 0u;
-            store_mask(a, step, mbits, lane);
-        }
+        if (cnt) store_mask(a, step, mbits, lane);
         if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
     } else {
         wave_total += cnt;
-        if (MODE == MODE_FLAGS) {                               // not used by the spec kernels; kept for completeness
-            const uint32_t rpl = 1u << rpl_log2;
-            for (uint32_t p = 0; p < 16; p++) {
-                const uint64_t row = step * kStepRows + (uint64_t)(p >> rpl_log2) * 64 * rpl + lane * rpl + (p & (rpl - 1));
-                if (row < n_rows) a.out_flags[row] = (uint8_t)((acc.p[p] >> lane) & 1ull);
-            }
-        }
     }
 }
 
@@ -554,18 +554,18 @@ __device__ __forceinline__ void eval_col_masks(const EvalArgs &a, int slot, cons
     }
 }
 
-template <int W, int RPL, int U>
+template <int W, int RPL, int U, int H>
 __device__ __forceinline__ void eval_col_chain(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, RowPlanes &acc) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
         uint64_t v[16];
         unpack64(raw, v, std::make_integer_sequence<int, 16>{});
-        for (uint32_t k = kb; k < ke; k++) chain_leaf<uint64_t>(v, a.lo[k], a.span[k], (a.chain_want >> k) & 1u, acc);
+        for (uint32_t k = kb; k < ke; k++) chain_leaf<uint64_t, H>(v, a.lo[k], a.span[k], (a.chain_want >> k) & 1u, acc);
     } else {
         uint32_t v[16];
         unpack32(raw, v, std::make_integer_sequence<int, 16>{});
         for (uint32_t k = kb; k < ke; k++)
-            chain_leaf<uint32_t>(v, (uint32_t)a.lo[k], (uint32_t)a.span[k], (a.chain_want >> k) & 1u, acc);
+            chain_leaf<uint32_t, H>(v, (uint32_t)a.lo[k], (uint32_t)a.span[k], (a.chain_want >> k) & 1u, acc);
     }
 }
 
@@ -597,12 +597,23 @@ struct RawStep {
         if constexpr (W1 != 0) r1.template load<NT>(a.col[1], lane_row0);
         if constexpr (W2 != 0) r2.template load<NT>(a.col[2], lane_row0);
     }
-    __device__ __forceinline__ void eval_chain(const EvalArgs &a, RowPlanes &acc) const {
+    template <int MODE, int H>
+    __device__ __forceinline__ void eval_chain_half(const EvalArgs &a, uint32_t &cnt, uint32_t &mbits) const {
+        RowPlanes acc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc.p[r] = ~0ull;
-        eval_col_chain<W0, RPL, U>(a, 0, r0, acc);
-        if constexpr (W1 != 0) eval_col_chain<W1, RPL, U>(a, 1, r1, acc);
-        if constexpr (W2 != 0) eval_col_chain<W2, RPL, U>(a, 2, r2, acc);
+        for (int r = 0; r < 8; r++) acc.p[r] = ~0ull;
+        eval_col_chain<W0, RPL, U, H>(a, 0, r0, acc);
+        if constexpr (W1 != 0) eval_col_chain<W1, RPL, U, H>(a, 1, r1, acc);
+        if constexpr (W2 != 0) eval_col_chain<W2, RPL, U, H>(a, 2, r2, acc);
+        fold_half<MODE, H>(a, acc, cnt, mbits);
+    }
+    template <int MODE>
+    __device__ __forceinline__ void eval_chain_emit(const EvalArgs &a, uint64_t step, uint32_t rpl_log2, uint32_t lane,
+                                                    uint64_t &wave_total) const {
+        uint32_t cnt = 0, mbits = 0;
+        eval_chain_half<MODE, 0>(a, cnt, mbits);
+        eval_chain_half<MODE, 1>(a, cnt, mbits);
+        emit_chain_step<MODE>(a, step, cnt, mbits, rpl_log2, lane, wave_total);
     }
     __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {     // <= 6 leaves: row-mask path
         LeafMasks lm;
@@ -685,9 +696,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i * n_waves;
             if (step >= full_steps) break;
-            RowPlanes acc;
-            A[i].eval_chain(a, acc);
-            emit_planes<MODE>(a, step, acc, log2i(RPL), n_rows, lane, wave_total);
+            A[i].template eval_chain_emit<MODE>(a, step, log2i(RPL), lane, wave_total);
         }
     }
     if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
