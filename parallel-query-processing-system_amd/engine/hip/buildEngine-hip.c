@@ -11,15 +11,19 @@
  * whole-file replication of buildEngine-mpi.c:71-127 (each GPU gets columns,
  * not records).
  */
+#define _DEFAULT_SOURCE
 #define _POSIX_C_SOURCE 200809L
 #include "buildEngine-hip.h"
 #include "hipPredicate.h"
 
+#include <malloc.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <sys/mman.h>
+#include <time.h>
 #include <unistd.h>
 
 /* ---- CSV ------------------------------------------------------------------ */
@@ -169,8 +173,19 @@ record **getAllRecordsFromFileHIP(const char *filepath, int *num_records, void *
     if (!start || !len) { fprintf(stderr, "Memory allocation failed\n"); free(text); free(start); free(len); return NULL; }
     const size_t n = chunks > 0 ? chunks - 1 : 0;        /* first chunk = header, dropped unconditionally */
 
-    record *block = malloc((n ? n : 1) * sizeof *block);
-    record **rows = malloc((n ? n : 1) * sizeof *rows);
+    /* head-room for INSERTs (untouched pages cost nothing); buildDeviceTableHIP learns the capacity
+     * from malloc_usable_size, so the block is still an ordinary malloc'd block to its owner */
+    const size_t cap_rows = n + n / 16 + 1024;
+    record *block = malloc(cap_rows * sizeof *block);
+    record **rows = malloc(cap_rows * sizeof *rows);
+    if (block && n * sizeof *block >= ((size_t)64 << 20)) {
+        /* a large row block is its own mapping: ask for huge pages on its 2 MiB-aligned interior before
+         * the first touch -- 1 M rows are 1 GB, and faulting in / releasing 260 k small pages costs
+         * more than parsing them (release alone: 126 ms, against 2 ms with huge pages) */
+        const uintptr_t lo = ((uintptr_t)block + (((uintptr_t)2 << 20) - 1)) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t hi = ((uintptr_t)block + n * sizeof *block) & ~(((uintptr_t)2 << 20) - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
+    }
     if (!block || !rows) { fprintf(stderr, "Memory allocation failed\n"); free(text); free(start); free(len); free(block); free(rows); return NULL; }
     struct parse_job job = { text, start + 1, len + 1, block };
     parallel_for(n, parse_range, &job);
@@ -468,6 +483,12 @@ bool buildDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
     t->row_block = engine->record_block;               /* block handed over by getAllRecordsFromFileHIP */
     t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 1);
+    if (t->row_block && engine->all_records) {                     /* what the two allocations really hold */
+        const size_t cap_block = malloc_usable_size(t->row_block) / sizeof(record);
+        const size_t cap_rows = malloc_usable_size(engine->all_records) / sizeof(record *);
+        const size_t cap = cap_block < cap_rows ? cap_block : cap_rows;
+        if (cap > t->row_capacity) t->row_capacity = cap;
+    }
     t->locks = calloc(1, sizeof *t->locks);
     if (!t->locks || pthread_rwlock_init(&t->locks->rows, NULL) != 0 || pthread_mutex_init(&t->locks->device, NULL) != 0) {
         perror("Failed to create engine locks");
@@ -578,8 +599,19 @@ void destroyDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = engine->record_block;
     if (!t) return;
     pqps_ctx *ctx = t->ctx;
+    const char *trace = getenv("PQPS_TRACE");
+    struct timespec t0, t1, t2, t3;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     free(t->row_block);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     hipTableFree(t, engine->num_indexes);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
     pqps_ctx_destroy(ctx);
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    if (trace && atoi(trace))
+        fprintf(stderr, "[pqps] destroy: host rows %.3f ms, device table %.3f ms, context %.3f ms\n",
+                (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6,
+                (double)(t2.tv_sec - t1.tv_sec) * 1e3 + (double)(t2.tv_nsec - t1.tv_nsec) * 1e-6,
+                (double)(t3.tv_sec - t2.tv_sec) * 1e3 + (double)(t3.tv_nsec - t2.tv_nsec) * 1e-6);
     engine->record_block = NULL;
 }

@@ -277,6 +277,8 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
 /* freeResultSet, S:881-908. */
 void freeResultSet(struct resultSetS *result) {
     if (!result) return;
+    const double t_free = now_seconds();
+    const long long cells = (long long)result->numRecords * result->numColumns;
     if (result->columnNames) {
         for (int j = 0; j < result->numColumns; j++) free(result->columnNames[j]);
         free(result->columnNames);
@@ -291,6 +293,7 @@ void freeResultSet(struct resultSetS *result) {
         free(result->data);
     }
     free(result);
+    TRACE("freeResultSet: %lld cells, %.3f ms\n", cells, (now_seconds() - t_free) * 1e3);
 }
 
 int isAttributeIndexed(struct engineS *engine, const char *attributeName) {
@@ -372,7 +375,9 @@ struct engineS *initializeEngineHIP(int num_indexes, const char *indexed_attribu
 
 void destroyEngineHIP(struct engineS *engine) {
     if (!engine) { fprintf(stderr, "Attempted to destroy a NULL engine pointer\n"); return; }
+    const double t_destroy = now_seconds();
     destroyDeviceTableHIP(engine);                                 /* frees the row block too */
+    TRACE("destroy: device table + context %.3f ms\n", (now_seconds() - t_destroy) * 1e3);
     free(engine->bplus_tree_roots);
     if (engine->indexed_attributes) {
         for (int i = 0; i < engine->num_indexes; i++) free(engine->indexed_attributes[i]);
