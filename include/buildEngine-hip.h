@@ -86,6 +86,11 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
 /* rows -> columns -> device.  Replaces engine->record_block (the row block
  * returned by getAllRecordsFromFileHIP) by the struct hipTable that owns it. */
 bool buildDeviceTableHIP(struct engineS *engine);
+/* Same, with the device context coming from a start-up begun earlier (hipBeginContextHIP runs
+ * pqps_ctx_create on a background thread: the HIP runtime needs ~0.2 s, the CSV parse can use them). */
+struct hipContextFuture;
+struct hipContextFuture *hipBeginContextHIP(void);
+bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *future);
 /* Re-creates columns, dictionaries and indexes from engine->all_records
  * (after INSERT / DELETE changed the host rows). */
 void rebuildDeviceTableHIP(struct engineS *engine);

@@ -346,9 +346,43 @@ static void *col_thread(void *p) {
     return NULL;
 }
 
+/* The HIP runtime takes ~0.2 s to come up; an engine that is about to parse a CSV starts that in the
+ * background (hipBeginContextHIP) and collects the context when the first device call is due. */
+struct hipContextFuture { pthread_t tid; bool threaded; pqps_ctx *ctx; int rc; int device; char err[256]; };
+
+static void *context_thread(void *p) {
+    struct hipContextFuture *f = p;
+    f->rc = pqps_ctx_create(f->device, &f->ctx);
+    if (f->rc != PQPS_OK) snprintf(f->err, sizeof f->err, "%s", pqps_last_error());   /* last_error is per thread */
+    return NULL;
+}
+
+struct hipContextFuture *hipBeginContextHIP(void) {
+    struct hipContextFuture *f = calloc(1, sizeof *f);
+    if (!f) { perror("Failed to allocate memory for device start-up"); exit(EXIT_FAILURE); }
+    const char *env = getenv("PQPS_DEVICE");
+    f->device = env ? atoi(env) : 0;
+    f->threaded = pthread_create(&f->tid, NULL, context_thread, f) == 0;
+    if (!f->threaded) context_thread(f);
+    return f;
+}
+
+static pqps_ctx *await_context(struct hipContextFuture *f) {
+    if (f->threaded) { pthread_join(f->tid, NULL); f->threaded = false; }
+    if (f->rc != PQPS_OK) {
+        fprintf(stderr, "HIP engine: cannot create a device context: %s\n", f->err);
+        exit(EXIT_FAILURE);
+    }
+    return f->ctx;
+}
+
+static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *future, record *const *rows, size_t n);
+
+struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) { return table_from_rows(ctx, NULL, rows, n); }
+
 /* Builds a device table from `n` host rows.  ctx may be shared (owned by the caller).
  * Capacity leaves head-room so that INSERT appends in place. */
-struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) {
+static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *future, record *const *rows, size_t n) {
     struct hipTable *t = calloc(1, sizeof *t);
     if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
     t->ctx = ctx;
@@ -374,6 +408,7 @@ struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) 
         for (int c = 0; c < HIPCOL_COUNT; c++) if (tid[c]) pthread_join(tid[c], NULL);
     }
     if (job.failed) { perror("Failed to build dictionary"); exit(EXIT_FAILURE); }
+    if (!ctx) { ctx = await_context(future); t->ctx = ctx; }   /* host staging above ran beside the device start-up */
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         const uint32_t width = t->col[c].width;
         void *dev = NULL;
@@ -475,12 +510,14 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
 }
 
 bool buildDeviceTableHIP(struct engineS *engine) {
-    pqps_ctx *ctx = NULL;
-    int device = 0;
-    const char *env = getenv("PQPS_DEVICE");
-    if (env) device = atoi(env);
-    if (pqps_ctx_create(device, &ctx) != PQPS_OK) hip_die("cannot create a device context");
-    struct hipTable *t = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
+    struct hipContextFuture *f = hipBeginContextHIP();
+    const bool ok = buildDeviceTableOnHIP(engine, f);
+    return ok;
+}
+
+bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *future) {
+    struct hipTable *t = table_from_rows(NULL, future, engine->all_records, (size_t)engine->num_records);
+    free(future);
     t->row_block = engine->record_block;               /* block handed over by getAllRecordsFromFileHIP */
     t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 1);
     if (t->row_block && engine->all_records) {                     /* what the two allocations really hold */
