@@ -178,6 +178,21 @@ int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int
 int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                       const uint8_t *delete_flags, uint64_t *kept_out, void *stream);
 
+/* Index mode across shards (no counterpart in the reference: its MPI engine replicates the table).
+ * A shard's index-mode result is ordered (key asc, row desc) within the shard; rows of a higher rank
+ * are higher rows, so the table-wide leaf order of engine/bplus.c:282-358 is the sort of the union by
+ * (key ascending, row descending).  pqps_gather_keys produces, for a result list, the order-preserving
+ * u64 image of each row's key (count read on the device, e.g. a slot header; signed i32 keys biased);
+ * pqps_merge_index_slots takes the all-gathered [count | ids] slots and the parallel key slots
+ * (`world` x (slot_stride - PQPS_SLOT_HEADER_WORDS) u64) and writes the merged order.  One probed
+ * condition per call; a query with several probed conditions (whose results the serial engine
+ * concatenates, duplicates included) merges each condition's segment with its own call.
+ * Synchronises the stream (the sort needs the total on the host). */
+int pqps_gather_keys(pqps_ctx *ctx, const pqps_column *col, int key_kind, const uint32_t *ids, const uint64_t *count_dev,
+                     uint64_t capacity, uint32_t id_base, uint64_t *keys_out, void *stream);
+int pqps_merge_index_slots(pqps_ctx *ctx, const uint32_t *slots, const uint64_t *key_slots, uint32_t world,
+                           uint64_t slot_stride, uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream);
+
 /* Tail of the all-gatherv merge.  A slot is what one rank's pqps_filter_scan produced when
  * given out_count = slot and out_ids = slot + PQPS_SLOT_HEADER_WORDS:
  *     [u64 match count][u64 reserved][u32 row IDs ...]

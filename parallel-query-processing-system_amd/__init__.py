@@ -236,6 +236,8 @@ def lib():
     L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
     L.pqps_bump_codes.argtypes = [vp, vp, u32, u64, u32, vp]
     L.pqps_compact_rows.argtypes = [vp, C.POINTER(Column), u32, u64, vp, C.POINTER(u64), vp]
+    L.pqps_gather_keys.argtypes = [vp, C.POINTER(Column), C.c_int, vp, vp, u64, u32, vp, vp]
+    L.pqps_merge_index_slots.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
     L.pqps_merge_slots.argtypes = [vp, vp, u32, u64, vp, u64, vp, vp]
     L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
     L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]

@@ -173,6 +173,44 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T *__restrict__ 
         dst[i] = src[keep[i]];
 }
 
+// ---- index mode across shards -----------------------------------------------------------------------
+// keys[i] = order-preserving u64 image of col[ids[i] - id_base] (signed i32 keys are biased so that
+// unsigned order = signed order); the count is read on the device (a slot header).
+template <typename T, bool SIGNED>
+__global__ __launch_bounds__(256) void gather_keys_kernel(const T *__restrict__ col, const uint32_t *__restrict__ ids,
+                                                          const uint64_t *count, uint64_t capacity, uint32_t id_base,
+                                                          uint64_t *__restrict__ keys) {
+    uint64_t n = *count;
+    if (n > capacity) n = capacity;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const T v = col[ids[i] - id_base];
+        keys[i] = SIGNED ? (uint64_t)((uint32_t)v ^ 0x80000000u) : (uint64_t)v;
+    }
+}
+
+// rank-order compaction of [count | ids] slots together with their parallel key slots
+__global__ __launch_bounds__(256) void compact_index_slots_kernel(const uint32_t *slots, const uint64_t *key_slots, uint32_t world,
+                                                                  uint64_t slot_stride, uint32_t *ids_out, uint64_t *keys_out,
+                                                                  uint64_t capacity, uint64_t *total_out) {
+    const uint32_t r = blockIdx.y;
+    const uint64_t seg_cap = slot_stride - 4;                       // kSlotHeaderWords
+    uint64_t displ = 0, total = 0, raw = 0;
+    for (uint32_t i = 0; i < world; i++) {
+        const uint64_t reported = *(const uint64_t *)(slots + (uint64_t)i * slot_stride);
+        const uint64_t c = reported < seg_cap ? reported : seg_cap;
+        if (i < r) displ += c;
+        total += c;
+        raw += reported;
+    }
+    const uint64_t mine = *(const uint64_t *)(slots + (uint64_t)r * slot_stride);
+    const uint64_t cnt = mine < seg_cap ? mine : seg_cap;
+    const uint32_t *src = slots + (uint64_t)r * slot_stride + 4;
+    const uint64_t *ksrc = key_slots + (uint64_t)r * seg_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
+        if (displ + i < capacity) { ids_out[displ + i] = src[i]; keys_out[displ + i] = ksrc[i]; }
+    if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) { total_out[0] = total; total_out[1] = raw; }
+}
+
 // ---- INSERT support: shift dictionary codes at or above a new value's rank -----------------
 template <typename T>
 __global__ void bump_codes_kernel(T *codes, uint64_t n, uint32_t threshold) {
@@ -905,6 +943,72 @@ int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, u
     }
     (void)hipFree(keep); (void)hipFree(count_dev); (void)hipFree(tmp);
     if (!rc) *kept_out = kept;
+    return rc;
+}
+
+int pqps_gather_keys(pqps_ctx *ctx, const pqps_column *col, int key_kind, const uint32_t *ids, const uint64_t *count_dev,
+                     uint64_t capacity, uint32_t id_base, uint64_t *keys_out, void *stream) {
+    if (!ctx || !col || !col->data || !ids || !count_dev || !keys_out) return fail(PQPS_EINVAL, "NULL argument");
+    if (key_kind == 1 && col->width != 4) return fail(PQPS_EINVAL, "signed keys must be 4 bytes wide");
+    hipStream_t s = pick_stream(ctx, stream);
+    uint64_t blocks = (capacity + 255) / 256;
+    if (blocks > (uint64_t)ctx->compute_units * 8) blocks = (uint64_t)ctx->compute_units * 8;
+    if (blocks == 0) blocks = 1;
+    const dim3 g((uint32_t)blocks), b(256);
+    if (key_kind == 1) hipLaunchKernelGGL((gather_keys_kernel<int32_t, true>), g, b, 0, s, (const int32_t *)col->data, ids, count_dev, capacity, id_base, keys_out);
+    else switch (col->width) {
+    case 1: hipLaunchKernelGGL((gather_keys_kernel<uint8_t, false>), g, b, 0, s, (const uint8_t *)col->data, ids, count_dev, capacity, id_base, keys_out); break;
+    case 2: hipLaunchKernelGGL((gather_keys_kernel<uint16_t, false>), g, b, 0, s, (const uint16_t *)col->data, ids, count_dev, capacity, id_base, keys_out); break;
+    case 4: hipLaunchKernelGGL((gather_keys_kernel<uint32_t, false>), g, b, 0, s, (const uint32_t *)col->data, ids, count_dev, capacity, id_base, keys_out); break;
+    case 8: hipLaunchKernelGGL((gather_keys_kernel<uint64_t, false>), g, b, 0, s, (const uint64_t *)col->data, ids, count_dev, capacity, id_base, keys_out); break;
+    default: return fail(PQPS_EINVAL, "width %u not in {1,2,4,8}", col->width);
+    }
+    HIP_TRY(hipGetLastError());
+    return PQPS_OK;
+}
+
+int pqps_merge_index_slots(pqps_ctx *ctx, const uint32_t *slots, const uint64_t *key_slots, uint32_t world,
+                           uint64_t slot_stride, uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream) {
+    if (!ctx || !slots || !key_slots || !merged || !totals) return fail(PQPS_EINVAL, "NULL argument");
+    if (world == 0 || world > 1024) return fail(PQPS_EINVAL, "world %u out of range", world);
+    if (slot_stride <= kSlotHeaderWords || (slot_stride & 1u)) return fail(PQPS_EINVAL, "slot stride %llu too small or odd", (unsigned long long)slot_stride);
+    if (((uintptr_t)slots & 7u) != 0) return fail(PQPS_EINVAL, "slots must be 8-byte aligned");
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t seg_cap = slot_stride - kSlotHeaderWords, cap = (uint64_t)world * seg_cap;
+    uint32_t *ids_a = nullptr, *ids_b = nullptr;
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    void *tmp = nullptr;
+    int rc = PQPS_OK;
+    hipError_t e = hipMalloc((void **)&ids_a, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&ids_b, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&keys_a, cap * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&keys_b, cap * sizeof(uint64_t));
+    uint64_t host_totals[2] = {0, 0};
+    if (e == hipSuccess) {
+        uint64_t bx = (slot_stride + 255) / 256;
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(compact_index_slots_kernel, dim3((uint32_t)bx, world), dim3(256), 0, s, slots, key_slots, world,
+                           slot_stride, ids_a, keys_a, cap, totals);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host_totals, totals, sizeof host_totals, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    const uint64_t n = host_totals[0] < merged_capacity ? host_totals[0] : merged_capacity;
+    if (e == hipSuccess && host_totals[0] > merged_capacity)
+        rc = fail(PQPS_EOVERFLOW, "merged capacity %llu too small for %llu IDs", (unsigned long long)merged_capacity, (unsigned long long)host_totals[0]);
+    if (e == hipSuccess && rc == PQPS_OK && n > 0) {
+        // global leaf order = (key ascending, row descending): two stable passes, minor criterion first
+        size_t t1 = 0, t2 = 0;
+        e = rocprim::radix_sort_pairs_desc(nullptr, t1, ids_a, ids_b, keys_a, keys_b, n, 0, 32, s);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t2, keys_b, keys_a, ids_b, merged, n, 0, 64, s);
+        const size_t tb = t1 > t2 ? t1 : t2;
+        if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc(tmp, t1, ids_a, ids_b, keys_a, keys_b, n, 0, 32, s);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t2, keys_b, keys_a, ids_b, merged, n, 0, 64, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(ids_a); (void)hipFree(ids_b); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(PQPS_EHIP, "index slot merge: %s", hipGetErrorString(e));
     return rc;
 }
 

@@ -115,6 +115,66 @@ class IdMerger:
         return self.merged[:int(tot[0])].cpu().numpy().view("uint32")
 
 
+class IndexMerger(IdMerger):
+    """Index mode across shards: every rank holds its shard's index-mode result, ordered
+    (key asc, row desc) inside the shard; the table-wide leaf order is the sort of the union by
+    (key asc, row desc).  Two all-gathers ([count | ids] slots, key slots) + pqps_merge_index_slots
+    (device sort) / numpy lexsort (CPU tensors).  One probed condition per merge."""
+
+    def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False):
+        super().__init__(torch, dist, world, rank, slot_capacity, device, ctx=ctx, pq=pq, host_staged=host_staged)
+        t = torch
+        self.keys_local = t.zeros(self.cap, dtype=t.int64, device=device)          # u64 payload
+        self.key_slots = t.zeros(world * self.cap, dtype=t.int64, device=device)
+
+    def set_local(self, ids_u32, keys_u64, count=None):
+        import numpy as np
+        super().set_local(ids_u32, count)
+        k = min(len(keys_u64), self.cap)
+        self.keys_local[:k] = self.torch.from_numpy(np.asarray(keys_u64[:k], dtype=np.uint64).view(np.int64).copy())
+
+    def gather_keys(self, column_array, key_kind, id_base, stream_ptr=None):
+        """Fills keys_local from the shard's key column for the IDs the filter left in the slot."""
+        self.pq.check(self.pq.lib().pqps_gather_keys(self.ctx.h, column_array, key_kind, self.ids_ptr, self.count_ptr,
+                                                     self.cap, id_base, self.keys_local.data_ptr(), stream_ptr), "pqps_gather_keys")
+
+    def merge(self, stream_ptr=None):
+        dist, t = self.dist, self.torch
+        if self.world == 1:
+            self.slots.copy_(self.slot_local)
+            self.key_slots.copy_(self.keys_local)
+        elif self.host_staged or self.device.type != "cuda":
+            loc, kloc = self.slot_local.cpu(), self.keys_local.cpu()
+            parts, kparts = [t.zeros_like(loc) for _ in range(self.world)], [t.zeros_like(kloc) for _ in range(self.world)]
+            dist.all_gather(parts, loc)
+            dist.all_gather(kparts, kloc)
+            self.slots.copy_(t.cat(parts))
+            self.key_slots.copy_(t.cat(kparts))
+        else:
+            dist.all_gather_into_tensor(self.slots, self.slot_local)
+            dist.all_gather_into_tensor(self.key_slots, self.keys_local)
+        if self.device.type == "cuda":
+            self.pq.check(self.pq.lib().pqps_merge_index_slots(
+                self.ctx.h, self.slots.data_ptr(), self.key_slots.data_ptr(), self.world, self.stride,
+                self.merged.data_ptr(), self.merged.numel(), self.totals.data_ptr(), stream_ptr), "pqps_merge_index_slots")
+        else:
+            import numpy as np
+            ids, keys, raw = [], [], 0
+            for r in range(self.world):
+                slot = self.slots[r * self.stride:(r + 1) * self.stride]
+                reported = int(slot[0:2].numpy().view("uint64")[0])
+                c = min(reported, self.cap)
+                ids.append(slot[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + c].numpy().view("uint32"))
+                keys.append(self.key_slots[r * self.cap:r * self.cap + c].numpy().view("uint64"))
+                raw += reported
+            ids, keys = np.concatenate(ids), np.concatenate(keys)
+            order = np.lexsort((-(ids.astype(np.int64)), keys))                 # key asc, then row desc
+            out = ids[order]
+            self.merged[:len(out)] = t.from_numpy(out.view(np.int32).copy())
+            self.totals[0] = len(out)
+            self.totals[1] = raw
+
+
 def default_rccl_library(torch=None):
     """The RCCL that goes with the HIP runtime this process runs on: under torch (which loads its
     own bundled libamdhip64 + librccl) the bundled one, otherwise the system one."""

@@ -369,3 +369,28 @@ class HostSynth:
         out = np.zeros(max(self.n, 1), dtype=np.uint32)
         k = lib.orc_scan_columns(C.byref(oc), wl.ptr, id_base, out.ctypes.data_as(C.POINTER(C.c_uint32)), self.n, nthreads)
         return out[:k]
+
+
+# ---- numpy restatement of the serial engine's index path (serial:358-474) over a HostSynth table ----
+def host_index_order(keys):
+    """(key asc, row desc): stable sort of the rows fed in descending order = B+-tree leaf order."""
+    import numpy as np
+    n = len(keys)
+    rev = np.arange(n - 1, -1, -1, dtype=np.int64)
+    return rev[np.argsort(keys[rev], kind="stable")]
+
+
+def host_index_select(host, perms, probes, chain, id_base=0):
+    """probes: [(column, key_lo, key_hi)] in chain order; candidates of each probe appended, then
+    re-filtered by the complete WHERE, order kept.  `perms[column]` = host_index_order of that column."""
+    import numpy as np
+    full = np.zeros(host.n, dtype=bool)
+    full[host.oracle_scan(chain)] = True
+    out = []
+    for name, lo, hi in probes:
+        perm = perms[name]
+        k = host.arr[name][perm]
+        b, e = np.searchsorted(k, lo, "left"), np.searchsorted(k, hi, "right")
+        cand = perm[b:max(b, e)]
+        out.append(cand[full[cand]] + id_base)
+    return np.concatenate(out).astype(np.uint32) if out else np.zeros(0, np.uint32)

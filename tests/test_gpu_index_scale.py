@@ -38,7 +38,7 @@ class DeviceIndex:
         self.ctx.free(self.keys)
 
 
-def index_select(ctx, table, probes, chain, out_ids, cap, scratch):
+def index_select(ctx, table, probes, chain, out_ids, cap, scratch, id_base=0):
     """probes: [(DeviceIndex, key_lo, key_hi)] in the order QPESeq would probe them."""
     pred, cols, nc, _ = table.bind(chain)
     count_dev, range_dev = scratch, scratch + 16
@@ -47,7 +47,7 @@ def index_select(ctx, table, probes, chain, out_ids, cap, scratch):
     for ix, lo, hi in probes:
         pq.check(L.pqps_index_probe(ctx.h, ix.keys, ix.width, 1 if ix.signed else 0, table.n,
                                     lo & 0xFFFFFFFFFFFFFFFF, hi & 0xFFFFFFFFFFFFFFFF, range_dev, None), "probe")
-        pq.check(L.pqps_filter_gather(ctx.h, cols, nc, ix.perm, range_dev, table.n, 0, C.byref(pred),
+        pq.check(L.pqps_filter_gather(ctx.h, cols, nc, ix.perm, range_dev, table.n, id_base, C.byref(pred),
                                       out_ids, cap, count_dev, None), "gather")
     ctx.sync()
     k = C.c_uint64()
@@ -58,24 +58,7 @@ def index_select(ctx, table, probes, chain, out_ids, cap, scratch):
     return ids[:min(k.value, cap)], k.value
 
 
-def host_index_order(keys):
-    """(key asc, row desc): stable sort of the rows fed in descending order."""
-    n = len(keys)
-    rev = np.arange(n - 1, -1, -1, dtype=np.int64)
-    return rev[np.argsort(keys[rev], kind="stable")]
-
-
-def host_index_select(host, perms, probes, chain):
-    full = np.zeros(host.n, dtype=bool)
-    full[host.oracle_scan(chain)] = True
-    out = []
-    for name, lo, hi in probes:
-        perm = perms[name]
-        k = host.arr[name][perm]
-        b, e = np.searchsorted(k, lo, "left"), np.searchsorted(k, hi, "right")
-        cand = perm[b:max(b, e)]
-        out.append(cand[full[cand]])
-    return np.concatenate(out).astype(np.uint32) if out else np.zeros(0, np.uint32)
+host_index_order, host_index_select = q.host_index_order, q.host_index_select
 
 
 I32_MIN, I32_MAX = -2**31, 2**31 - 1
@@ -146,3 +129,57 @@ def test_index_probe_100m_properties(ctx):
         ctx.free(p)
     ix.free()
     dev.free()
+
+
+@pytest.mark.parametrize("name,signed,lo,hi,chain", [
+    ("risk_level", True, 4, I32_MAX, [("risk_level", ">", "3"), "AND", ("exit_code", "=", "0")]),
+    ("user_id", True, 1001, 1003, [("user_id", ">=", "1001"), "AND", ("user_id", "<=", "1003")]),
+    ("command_id", False, 1_500_000, 2**64 - 1, [("command_id", ">=", "1500000"), "AND", ("sudo_used", "=", "FALSE")]),
+])
+def test_index_mode_merge_across_shards(ctx, name, signed, lo, hi, chain):
+    """SURVEY 8(e), index mode across shards: 8 row-range shards each answer the probe from their own
+    index (leaf order inside the shard), the [count | ids] slots and the key slots are laid out as the
+    all-gathers deliver them, and pqps_merge_index_slots must reproduce the WHOLE table's leaf order
+    (key asc, row desc) -- i.e. exactly what the single-table index path returns."""
+    n, world, seed, hdr = 2_000_003, 8, 31, pq.SLOT_HEADER_WORDS
+    L = pq.lib()
+    whole = pq.SyntheticTable(ctx, n, seed=seed)
+    wix = DeviceIndex(ctx, whole, name, signed)
+    out = ctx.malloc(4 * n)
+    scratch = ctx.malloc(256)
+    want, k_want = index_select(ctx, whole, [(wix, lo, hi)], chain, out, n, scratch)
+    assert k_want == len(want) > 1000
+    wix.free()
+    whole.free()
+
+    cap = (n // world + 1026) & ~1                       # a shard can contribute all of its rows
+    stride = cap + hdr
+    slots = ctx.malloc(world * stride * 4)
+    keys = ctx.malloc(world * cap * 8)
+    ctx.memset(slots, 0, world * stride * 4)
+    for r in range(world):
+        s_, c_ = C.c_uint64(), C.c_uint64()
+        L.pqps_partition(n, world, r, C.byref(s_), C.byref(c_))
+        start, count = s_.value, c_.value
+        shard = pq.SyntheticTable(ctx, count, seed=seed, row0=start)
+        six = DeviceIndex(ctx, shard, name, signed)
+        slot = slots + r * stride * 4
+        got, k = index_select(ctx, shard, [(six, lo, hi)], chain, slot + 4 * hdr, cap, scratch, id_base=start)
+        assert k <= cap
+        ctx.upload(slot, C.byref(C.c_uint64(k)), 8)
+        col = pq.column_array([(shard.ptr[name], shard.width[name])])
+        pq.check(L.pqps_gather_keys(ctx.h, col, 1 if signed else 0, slot + 4 * hdr, slot, cap, start, keys + r * cap * 8, None), "gather keys")
+        ctx.sync()
+        six.free()
+        shard.free()
+    merged = ctx.malloc(4 * world * cap)
+    totals = ctx.malloc(16)
+    pq.check(L.pqps_merge_index_slots(ctx.h, slots, keys, world, stride, merged, world * cap, totals, None), "index merge")
+    t = (C.c_uint64 * 2)()
+    ctx.download(t, totals, 16)
+    assert t[0] == t[1] == k_want
+    got = np.zeros(k_want, dtype=np.uint32)
+    ctx.download(got.ctypes.data, merged, 4 * k_want)
+    assert np.array_equal(got, want)
+    for p_ in (slots, keys, merged, totals, out, scratch):
+        ctx.free(p_)
