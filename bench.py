@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange step: 'rccl' = the shim calls ncclAllGather itself (one host call per query); "
                          "'torch' = torch.distributed collectives from Python (also the gloo rehearsal path)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N=1: every query's K1, K2, K3 on one stream (no overlap of K2/K3 with the next query's K1)")
     ap.add_argument("--force-merge", action="store_true",
                     help="N=1 rehearsal: run the N>1 exchange step (RCCL all-gather + merge, second stream) with a world of 1")
     args = ap.parse_args()
@@ -225,6 +227,11 @@ def main():
     slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096
     del cal_ids
     native = exchange and args.exchange == "rccl" and args.backend == "nccl"
+    # N = 1: a stream of queries -- K2 / K3 of query k run on a second stream under K1 of query k+1
+    qs = None
+    if not exchange and not args.no_pipeline:
+        qs = C.c_void_p()
+        pq.check(L.pqps_qstream_create(ctx.h, RING, C.byref(qs)), "pqps_qstream_create")
     xch, mergers = None, None
     if native:
         xch = mg.ShardExchange(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING)
@@ -244,6 +251,10 @@ def main():
         m = mergers[r]
         # slot r is free again once the merge that last used it (query k - RING) has finished: a host-side
         # wait, normally already satisfied, so the scan stream carries no cross-stream barrier packet
+        if qs is not None:
+            pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap, m.count_ptr, sptr),
+                     "pqps_qstream_scan")
+            return
         merge_done[r].synchronize()
         pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap,
                                     m.count_ptr, sptr), "pqps_filter_scan")
@@ -322,6 +333,7 @@ def main():
                    "query": sql, "rows_per_gpu": args.rows, "rows_total": n_global,
                    "matches_total": total_matches, "selectivity": total_matches / n_global,
                    "bytes_per_row": bytes_per_row,
+                   "pipelining": ("K2/K3 (+ exchange) of query k on a second stream under K1 of query k+1" if (qs is not None or native) else "none: K1, K2, K3 of a query back to back on one stream"),
                    "parallelism": f"row-range shards x{world}" + (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} [count|IDs] all-gather + device merge per query on every rank ({'shim-driven' if native else 'torch.distributed'})" if exchange else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -337,6 +349,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)
     if xch is not None:
         xch.close()
+    if qs is not None:
+        pq.check(L.pqps_qstream_destroy(qs), "pqps_qstream_destroy")
     if exchange:
         dist.barrier()
         dist.destroy_process_group()

@@ -206,6 +206,23 @@ int pqps_merge_index_slots(pqps_ctx *ctx, const uint32_t *slots, const uint64_t 
 int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint64_t slot_stride,
                      uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream);
 
+/* ---- a stream of queries on one GPU ------------------------------------------------------------------
+ * The scan kernel (K1) is bandwidth-bound, the compaction behind it (K2, K3: ~12 us) latency-bound.
+ * pqps_qstream_scan is pqps_filter_scan with the two on different streams: K1 on `scan_stream`, K2 / K3 on
+ * the query stream's own stream behind K1's completion event, each of the `depth` queries in flight with
+ * its own scratch -- so a caller issuing query after query keeps the scan stream busy with K1s back to
+ * back (the reference's OpenMP driver issues its queries concurrently, QPEOMP.c:234-291).  Results are
+ * complete after pqps_qstream_sync() (or a stream / device synchronise); every query in flight needs its
+ * own out_ids / out_count.  The call blocks on the host only to reuse the scratch of the query `depth`
+ * calls back. */
+typedef struct pqps_qstream pqps_qstream;
+int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out);
+int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                      const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
+                      void *scan_stream);
+int pqps_qstream_sync(pqps_qstream *q);
+int pqps_qstream_destroy(pqps_qstream *q);
+
 /* ---- multi-GPU SELECT: shard scan + ONE RCCL all-gather + device merge, one host call per query ----
  * Replaces the exchange step of engine/mpi/executeEngine-mpi.c:717-768 (local scan of the rank's row
  * range, MPI_Allgather of the sizes, MPI_Allgatherv of the payload).  One process per GPU; every rank

@@ -239,6 +239,10 @@ def lib():
     L.pqps_gather_keys.argtypes = [vp, C.POINTER(Column), C.c_int, vp, vp, u64, u32, vp, vp]
     L.pqps_merge_index_slots.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
     L.pqps_merge_slots.argtypes = [vp, vp, u32, u64, vp, u64, vp, vp]
+    L.pqps_qstream_create.argtypes = [vp, u32, C.POINTER(vp)]
+    L.pqps_qstream_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
+    L.pqps_qstream_sync.argtypes = [vp]
+    L.pqps_qstream_destroy.argtypes = [vp]
     L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
     L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]
     L.pqps_exchange_select.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), u32, vp]

@@ -467,10 +467,14 @@ uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps, bool streaming, uint32_t steps
 // K1 (+ K2 + K3 for ID output).  `rows` = scan rows or the gather upper bound.
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
-               hipEvent_t done = nullptr) {
+               hipEvent_t done = nullptr, hipStream_t compact = nullptr, hipEvent_t k1_done = nullptr) {
     // `done` (optional) becomes ready when the last kernel of this query has finished.  It rides on
     // that kernel's own dispatch packet: a separate hipEventRecord would put a barrier packet behind
     // it and cost the NEXT query on this stream ~7 us of idle queue.
+    // `compact` (optional, ID output): K2 and K3 run on that stream behind K1's own completion event
+    // `k1_done`, so that the caller's stream is free for the next query's K1 at once -- the ~12 us of
+    // latency-bound compaction then hide under the next bandwidth-bound scan (the caller gives every
+    // query in flight its own ctx = its own scratch).
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
@@ -482,14 +486,18 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.n_super = (uint32_t)((groups + kSuperGroups - 1) / kSuperGroups);
     const uint32_t grid = eval_grid(ctx, steps, a.streaming != 0, a.steps_per_iter);
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
-    if (timed) {
-        // the two events are attached to the dispatch itself: they carry the kernel's own begin /
-        // end timestamps (what rocprofv3 --kernel-trace reports), not the queueing around it
-        hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, ctx->ev_start[ctx->timed], ctx->ev_eval[ctx->timed], 0, a);
+    const bool split = compact != nullptr && compact != s && mode == MODE_IDS && (timed || k1_done != nullptr);
+    if (timed || split) {
+        // the events are attached to the dispatch itself: they carry the kernel's own begin / end
+        // timestamps (what rocprofv3 --kernel-trace reports), not the queueing around it
+        hipEvent_t k1_stop = timed ? ctx->ev_eval[ctx->timed] : k1_done;
+        hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, k1_stop, 0, a);
+        HIP_TRY(hipGetLastError());
+        if (split) { HIP_TRY(hipStreamWaitEvent(compact, k1_stop, 0)); s = compact; }   // everything below runs there
     } else {
         hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     if (mode != MODE_IDS) {
         if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, out_count);
         else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, out_count);
@@ -1083,7 +1091,8 @@ struct pqps_exchange {
     uint32_t *slots;                 // [ring][world][stride]   gathered
     uint32_t *merged;                // [ring][world * cap]
     uint64_t *totals;                // [ring][2]
-    hipEvent_t *scan_done, *merge_done;
+    hipEvent_t *scan_done, *k1_done, *merge_done;
+    pqps_ctx **child;                // [ring] a context (= filter scratch) per query in flight
     bool *used;
 };
 
@@ -1102,10 +1111,12 @@ int pqps_exchange_destroy(pqps_exchange *x) {
     if (x->stream) (void)hipStreamSynchronize(x->stream);
     if (x->comm) (void)x->rccl.CommDestroy(x->comm);
     for (uint32_t i = 0; i < x->ring; i++) {
-        if (x->scan_done) (void)hipEventDestroy(x->scan_done[i]);
-        if (x->merge_done) (void)hipEventDestroy(x->merge_done[i]);
+        if (x->scan_done && x->scan_done[i]) (void)hipEventDestroy(x->scan_done[i]);
+        if (x->k1_done && x->k1_done[i]) (void)hipEventDestroy(x->k1_done[i]);
+        if (x->merge_done && x->merge_done[i]) (void)hipEventDestroy(x->merge_done[i]);
+        if (x->child && x->child[i]) pqps_ctx_destroy(x->child[i]);
     }
-    delete[] x->scan_done; delete[] x->merge_done; delete[] x->used;
+    delete[] x->scan_done; delete[] x->k1_done; delete[] x->merge_done; delete[] x->child; delete[] x->used;
     if (x->local) (void)hipFree(x->local);
     if (x->slots) (void)hipFree(x->slots);
     if (x->merged) (void)hipFree(x->merged);
@@ -1138,10 +1149,13 @@ int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rcc
     X_TRY(hipMalloc((void **)&x->totals, (size_t)ring * 2 * sizeof(uint64_t)));
     X_TRY(hipMemset(x->local, 0, (size_t)ring * x->stride * 4));
     X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
-    x->scan_done = new hipEvent_t[ring](); x->merge_done = new hipEvent_t[ring](); x->used = new bool[ring]();
+    x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->merge_done = new hipEvent_t[ring]();
+    x->child = new pqps_ctx *[ring](); x->used = new bool[ring]();
     for (uint32_t i = 0; i < ring; i++) {
         X_TRY(hipEventCreateWithFlags(&x->scan_done[i], hipEventDisableTiming));
+        X_TRY(hipEventCreateWithFlags(&x->k1_done[i], hipEventDisableTiming));
         X_TRY(hipEventCreateWithFlags(&x->merge_done[i], hipEventDisableTiming));
+        if (pqps_ctx_create(ctx->device, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
     }
 #undef X_TRY
     int nrc = x->rccl.CommInitRank(&x->comm, (int)world, *id, (int)rank);
@@ -1172,10 +1186,16 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    rc = run_filter(x->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
-                    local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan, x->scan_done[slot]);
+    // K1 on the caller's stream; K2, K3, the all-gather and the merge on the exchange stream behind K1's
+    // completion event, with this slot's own scratch: the caller's stream is free for the next query's K1
+    // at once.  (While the context records timings, the scan runs whole on the caller's stream with the
+    // context's own scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.)
+    const bool timed = x->ctx->timing;
+    rc = run_filter(timed ? x->ctx : x->child[slot], pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS,
+                    false, id_base, local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan,
+                    timed ? x->scan_done[slot] : nullptr, timed ? nullptr : x->stream, timed ? nullptr : x->k1_done[slot]);
     if (rc) return rc;
-    HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    if (timed) HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
     int nrc = x->rccl.AllGather(local, slots, (size_t)x->stride, kRcclInt32, x->comm, x->stream);   // mpi:753 + mpi:765
     if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
     rc = pqps_merge_slots(x->ctx, slots, x->world, x->stride, x->merged + (uint64_t)slot * x->world * x->cap,
@@ -1228,6 +1248,83 @@ int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merge
 int pqps_exchange_sync(pqps_exchange *x) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
     HIP_TRY(hipStreamSynchronize(x->stream));
+    return PQPS_OK;
+}
+
+// ---- a stream of queries on one GPU: K1 of query k+1 over K2 / K3 of query k ----------------------
+struct pqps_qstream {
+    pqps_ctx *ctx;
+    uint32_t depth;
+    uint64_t seq;
+    hipStream_t compact;             // where K2 / K3 run
+    pqps_ctx **child;                // [depth] scratch of the queries in flight
+    hipEvent_t *k1_done, *done;
+    bool *used;
+};
+
+int pqps_qstream_destroy(pqps_qstream *q) {
+    if (!q) return PQPS_OK;
+    if (q->compact) (void)hipStreamSynchronize(q->compact);
+    for (uint32_t i = 0; i < q->depth; i++) {
+        if (q->k1_done && q->k1_done[i]) (void)hipEventDestroy(q->k1_done[i]);
+        if (q->done && q->done[i]) (void)hipEventDestroy(q->done[i]);
+        if (q->child && q->child[i]) pqps_ctx_destroy(q->child[i]);
+    }
+    delete[] q->k1_done; delete[] q->done; delete[] q->child; delete[] q->used;
+    if (q->compact) (void)hipStreamDestroy(q->compact);
+    delete q;
+    return PQPS_OK;
+}
+
+int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
+    if (!ctx || !out) return fail(PQPS_EINVAL, "NULL argument");
+    if (depth < 2 || depth > 16) return fail(PQPS_EINVAL, "depth %u out of range (2..16)", depth);
+    pqps_qstream *q = new (std::nothrow) pqps_qstream();
+    if (!q) return fail(PQPS_ENOMEM, "out of host memory");
+    q->ctx = ctx; q->depth = depth;
+    q->child = new pqps_ctx *[depth](); q->k1_done = new hipEvent_t[depth](); q->done = new hipEvent_t[depth]();
+    q->used = new bool[depth]();
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->compact, hipStreamNonBlocking);
+    for (uint32_t i = 0; i < depth && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&q->k1_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
+        if (e == hipSuccess && pqps_ctx_create(ctx->device, &q->child[i]) != PQPS_OK) { pqps_qstream_destroy(q); return PQPS_EHIP; }
+    }
+    if (e != hipSuccess) { pqps_qstream_destroy(q); return fail(PQPS_EHIP, "query stream: %s", hipGetErrorString(e)); }
+    *out = q;
+    return PQPS_OK;
+}
+
+int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                      const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
+                      void *scan_stream) {
+    if (!q || !out_count) return fail(PQPS_EINVAL, "qstream/out_count is NULL");
+    if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
+    if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
+        return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
+    int rc = check_pred(cols, n_cols, pred);
+    if (rc) return rc;
+    const uint32_t slot = (uint32_t)(q->seq % q->depth);
+    // this slot's scratch is free once the compaction that last used it has finished (a host wait,
+    // `depth` queries back -- normally long satisfied)
+    if (q->used[slot]) HIP_TRY(hipEventSynchronize(q->done[slot]));
+    EvalArgs a;
+    fill_args(a, cols, n_cols, pred);
+    a.n_rows = n_rows;
+    hipStream_t scan = pick_stream(q->ctx, scan_stream);
+    const bool timed = q->ctx->timing;                           // see pqps_exchange_select
+    rc = run_filter(timed ? q->ctx : q->child[slot], pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS,
+                    false, id_base, out_ids, out_capacity, out_count, scan, timed ? nullptr : q->done[slot],
+                    timed ? nullptr : q->compact, timed ? nullptr : q->k1_done[slot]);
+    if (rc) return rc;
+    if (!timed) { q->used[slot] = true; q->seq++; }
+    return PQPS_OK;
+}
+
+int pqps_qstream_sync(pqps_qstream *q) {
+    if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    HIP_TRY(hipStreamSynchronize(q->compact));
     return PQPS_OK;
 }
 

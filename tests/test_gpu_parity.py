@@ -245,6 +245,48 @@ def test_native_exchange_world_of_one(ctx):
         dev.free()
 
 
+def test_query_stream_keeps_queries_apart(ctx):
+    """pqps_qstream_*: K1 of query k+1 runs while K2 / K3 of query k are still compacting on the
+    second stream.  40 queries of 6 different shapes (sparse, dense, > 6 leaves -> generic kernel,
+    empty) go through a depth-3 stream back to back, each with its own output buffer; every answer
+    must equal the oracle's, and a sync in the middle must not disturb the sequence."""
+    L = pq.lib()
+    n = 700_001
+    host = q.HostSynth(n, seed=17)
+    dev = pq.SyntheticTable(ctx, n, seed=17)
+    names = ["S1", "Q_A", "seven_leaves", "none", "Q_C", "S7"]
+    want = {k: host.oracle_scan(QUERIES[k]) for k in names}
+    bound = {k: dev.bind(QUERIES[k]) for k in names}
+    qs = C.c_void_p()
+    pq.check(L.pqps_qstream_create(ctx.h, 3, C.byref(qs)), "pqps_qstream_create")
+    assert L.pqps_qstream_create(ctx.h, 1, C.byref(C.c_void_p())) == -1           # depth >= 2
+    outs = [DeviceOut(ctx, n) for _ in range(8)]
+    try:
+        order = [names[(3 * i + i // 5) % len(names)] for i in range(40)]
+        for base in range(0, 40, 8):                                  # 8 queries in flight per batch of buffers
+            for j, name in enumerate(order[base:base + 8]):
+                pred, cols, nc, _ = bound[name]
+                pq.check(L.pqps_qstream_scan(qs, cols, nc, n, 0, C.byref(pred), outs[j].ids, outs[j].cap, outs[j].count, None),
+                         "pqps_qstream_scan")
+            pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
+            ctx.sync()
+            for j, name in enumerate(order[base:base + 8]):
+                k = outs[j].read_count()
+                assert k == len(want[name]) and np.array_equal(outs[j].read_ids(k), want[name]), (base + j, name)
+        # capacity overflow is still reported through the count, nothing is written past the buffer
+        pred, cols, nc, _ = bound["Q_A"]
+        small = DeviceOut(ctx, 100)
+        pq.check(L.pqps_qstream_scan(qs, cols, nc, n, 0, C.byref(pred), small.ids, 100, small.count, None))
+        pq.check(L.pqps_qstream_sync(qs))
+        assert small.read_count() == len(want["Q_A"]) and np.array_equal(small.read_ids(100), want["Q_A"][:100])
+        small.free()
+    finally:
+        pq.check(L.pqps_qstream_destroy(qs))
+        for o in outs:
+            o.free()
+        dev.free()
+
+
 def test_shim_rejects_malformed_calls(ctx):
     """Every shape the kernels assume is checked on the host first: a bad call returns PQPS_EINVAL
     with a message and launches nothing (a kernel fault can take the whole GPU down)."""
