@@ -339,6 +339,90 @@ def main():
     print(f"parse cases: {len(parse_out)}")
 
 
+def random_where_cases(csv2k, n_cases, seed):
+    """Seeded random WHERE trees over all 12 columns: literals drawn from the table itself (so that
+    predicates match something), every operator, AND / OR mixes without precedence, parenthesised
+    sub-chains two levels deep, the 5-conditions-per-level quirk.  Only tokens the reference's parser
+    handles deterministically: non-negative digit runs, double-quoted strings without quote / comment
+    characters, TRUE / FALSE / 1 / 0."""
+    import csv as csvmod
+    import random
+    import re
+    rng = random.Random(seed)
+    with open(csv2k, newline="", encoding="latin-1") as f:
+        rows = list(csvmod.DictReader(f))
+    numeric = ["command_id", "exit_code", "user_id", "risk_level"]
+    strings = ["raw_command", "base_command", "shell_type", "timestamp", "working_directory", "user_name", "host_name"]
+    safe = re.compile(r"^[A-Za-z0-9_./: @=+,~-]+$")
+    pool = {c: sorted({r[c] for r in rows if safe.match(r[c]) and "--" not in r[c]}) for c in strings}
+    pool.update({c: sorted({r[c] for r in rows}, key=int) for c in numeric})
+    ops = ["=", "!=", "<", "<=", ">", ">="]
+
+    def condition():
+        kind = rng.random()
+        if kind < 0.45:
+            c = rng.choice(numeric)
+            v = rng.choice(pool[c]) if rng.random() < 0.8 else str(rng.randrange(0, 3000))
+            return f"{c} {rng.choice(ops)} {v}"
+        if kind < 0.85:
+            c = rng.choice(strings)
+            v = rng.choice(pool[c])
+            if rng.random() < 0.15:
+                v = v[:max(1, len(v) // 2)]                           # a prefix: range semantics of strcmp
+            return f'{c} {rng.choice(ops)} "{v}"'
+        return f"sudo_used {rng.choice(['=', '=', '!=', '<', '>='])} {rng.choice(['TRUE', 'FALSE', '1', '0'])}"
+
+    def chain(depth):
+        k = rng.choice([1, 2, 2, 3, 3, 4, 5] if depth == 0 else [1, 2, 2, 3])
+        parts = []
+        for i in range(k):
+            if depth < 2 and rng.random() < 0.25:
+                parts.append("(" + chain(depth + 1) + ")")
+            else:
+                parts.append(condition())
+            if i + 1 < k:
+                parts.append(rng.choice(["AND", "OR"]))
+        return " ".join(parts)
+
+    all_cols = numeric + strings + ["sudo_used"]
+    cases = []
+    for i in range(n_cases):
+        sel = "*" if rng.random() < 0.2 else ", ".join(rng.sample(all_cols, rng.randint(1, 5)))
+        cases.append((f"R{i:03d}", sel, chain(0)))
+    return cases
+
+
+def random_goldens(csv2k, n_cases=220, seed=20260101):
+    """select_random_golden.json: the random WHERE trees through the REAL reference (scan mode and the
+    default five indexes).  Cases whose candidate list would overflow the reference's buffer
+    (heap corruption there) are dropped, so every entry is pinned."""
+    ref = q.load_ref()
+    q.build_oracle()
+    out, dropped = [], 0
+    engines = {cfg: q.RefEngine(csv2k, INDEX_CONFIGS[cfg]) for cfg in ("none", "default")}
+    oracles = {cfg: q.OracleTable(csv2k, INDEX_CONFIGS[cfg]) for cfg in ("none", "default")}
+    for name, sel, where in random_where_cases(csv2k, n_cases, seed):
+        sql = compose(sel, where)
+        head, chain = parse_with_ref(ref, sql)
+        for cfg in ("none", "default"):
+            eng, orc = engines[cfg], oracles[cfg]
+            o_ids, o_count, cand = orc.select_ids(chain)
+            if cand > eng.n:
+                dropped += 1
+                continue
+            res = eng.select(sql)
+            r2 = eng.select(compose("command_id", where))
+            out.append({"name": name, "csv": csv2k.name, "indexes": cfg, "sql": sql, "where": q.chain_to_jsonable(chain),
+                        "candidates": cand, "pinned": True, "num_records": res["numRecords"], "columns": res["columns"],
+                        "rows_sha256": sha_rows(res["rows"]),
+                        "ids_zlib_b64": q.pack_ids([int(r[0]) for r in r2["rows"]])})
+    for e in engines.values():
+        e.close()
+    (HERE / "select_random_golden.json").write_text(json.dumps(out, separators=(",", ":")))
+    nonempty = sum(1 for c in out if c["num_records"] > 0)
+    print(f"random select cases: {len(out)} pinned ({nonempty} with matches), {dropped} dropped (candidate overflow)")
+
+
 def driver_goldens(csv2k):
     """End-to-end driver goldens: the reference's QPESeq on its own sample-queries.txt and
     sample-queries-FULL.txt (which adds Sample 6, the DELETE).  The driver always opens
@@ -365,5 +449,7 @@ if __name__ == "__main__":
     import sys
     if "--driver-only" in sys.argv:
         driver_goldens(HERE / "commands_2k.csv")
+    elif "--random-only" in sys.argv:
+        random_goldens(HERE / "commands_2k.csv")
     else:
         main()

@@ -394,3 +394,21 @@ def host_index_select(host, perms, probes, chain, id_base=0):
         cand = perm[b:max(b, e)]
         out.append(cand[full[cand]] + id_base)
     return np.concatenate(out).astype(np.uint32) if out else np.zeros(0, np.uint32)
+
+
+# ---- golden ID lists: plain JSON lists (select_golden.json) or zlib + base64 of the uint32 array ----
+def pack_ids(ids):
+    import base64, zlib
+    import numpy as np
+    return base64.b64encode(zlib.compress(np.asarray(ids, dtype=np.uint32).tobytes(), 9)).decode()
+
+
+def case_ids(case):
+    """The expected row-ID list of a golden SELECT case, or None if the case carries none."""
+    if "ids" in case:
+        return list(case["ids"])
+    if "ids_zlib_b64" in case:
+        import base64, zlib
+        import numpy as np
+        return np.frombuffer(zlib.decompress(base64.b64decode(case["ids_zlib_b64"])), dtype=np.uint32).tolist()
+    return None

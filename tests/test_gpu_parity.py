@@ -25,7 +25,8 @@ import qpelib as q
 pq = q.pq
 pytestmark = pytest.mark.gpu
 
-SELECT = json.loads((q.GOLDEN / "select_golden.json").read_text())
+SELECT = (json.loads((q.GOLDEN / "select_golden.json").read_text())
+          + json.loads((q.GOLDEN / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
 INDEX_CONFIGS = {
     "none": [],
     "default": pq.DEFAULT_INDEXES,
@@ -487,8 +488,8 @@ def test_engine_select_matches_reference_golden(case):
     chain = q.chain_from_jsonable(case["where"])
     ids = eng.select_ids(chain)
     assert len(ids) == case["num_records"]
-    if "ids" in case:
-        assert ids == case["ids"]
+    if q.case_ids(case) is not None:
+        assert ids == q.case_ids(case)
     sql = case["sql"]
     sel = sql[len("SELECT "):sql.index(" FROM ")]
     cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]

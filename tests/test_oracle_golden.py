@@ -17,7 +17,8 @@ import pytest
 import qpelib as q
 
 GOLD = q.GOLDEN
-SELECT = json.loads((GOLD / "select_golden.json").read_text())
+SELECT = (json.loads((GOLD / "select_golden.json").read_text())
+          + json.loads((GOLD / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
 INDEX_CONFIGS = {
     "none": [],
     "default": q.DEFAULT_INDEXES,
@@ -54,8 +55,8 @@ def test_select_matches_reference(case):
     ids, count, cand = t.select_ids(chain)
     assert count == case["num_records"]
     assert cand == case["candidates"]
-    if "ids" in case:
-        assert ids == case["ids"]
+    if q.case_ids(case) is not None:
+        assert ids == q.case_ids(case)
     sql = case["sql"]
     sel = sql[len("SELECT "):sql.index(" FROM ")]
     cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]

@@ -13,7 +13,8 @@ import kernel_model as km
 import qpelib as q
 
 pq = q.pq
-SELECT = json.loads((q.GOLDEN / "select_golden.json").read_text())
+SELECT = (json.loads((q.GOLDEN / "select_golden.json").read_text())
+          + json.loads((q.GOLDEN / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
 _cache = {}
 
 
