@@ -1,6 +1,7 @@
 /* parseDump.c -- text dumps of what the SQL front end hands to the engine.
- * Debug / test aid exported from libpqps_hip.so: the format matches
- * oracle/ref_harness.c so the same golden strings pin both front ends. */
+ * Debug / test aid exported from libpqps_hip.so: the format is the one the
+ * tests' harness around the reference build prints, so the same golden
+ * strings (tests/golden/parse_golden.json) pin both front ends. */
 #include <stdio.h>
 #include <string.h>
 

@@ -82,3 +82,29 @@ def test_partition_matches_mpi_formula():
                 lib.pqps_partition(n, world, r, C.byref(s1), C.byref(c1))
                 orc.orc_partition(n, world, r, C.byref(s2), C.byref(c2))
                 assert (s1.value, c1.value) == (s2.value, c2.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing in the package or the public headers may include,
+    import, link or load it (and there is no CPU fallback to route through)."""
+    import re
+    import subprocess
+    pat = re.compile(r"qpe_oracle|libqpe_oracle|oracle/|orc_[a-z_]+\(|_ref/|libqpeseq_ref")
+    offenders = []
+    for base in (q.PKG, q.ROOT / "include"):
+        for path in base.rglob("*"):
+            if path.is_file() and path.suffix in {".c", ".h", ".hpp", ".hip", ".py", ""} and "build" not in path.parts \
+                    and path.name not in {"QPEHIP"} and path.suffix != ".so":
+                try:
+                    text = path.read_text(encoding="latin-1")
+                except OSError:
+                    continue
+                if path.name == "Makefile" or path.suffix:
+                    for i, line in enumerate(text.splitlines(), 1):
+                        if pat.search(line) and "checker" not in line:
+                            offenders.append(f"{path.relative_to(q.ROOT)}:{i}: {line.strip()[:100]}")
+    assert not offenders, offenders
+    lib = q.PKG / "libpqps_hip.so"
+    if lib.exists():
+        needed = subprocess.run(["readelf", "-d", str(lib)], capture_output=True, text=True).stdout
+        assert "oracle" not in needed and "qpeseq" not in needed
