@@ -102,6 +102,9 @@ const char *pqps_last_error(void);
  * counts; grown on demand).  One query at a time per context; use one context per host thread. */
 int  pqps_ctx_create(int device, pqps_ctx **out);
 void pqps_ctx_destroy(pqps_ctx *ctx);
+/* Allocates the filter scratch for tables of up to n_rows now (otherwise the first query does it:
+ * half a dozen device allocations, several ms). */
+int  pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
 /* Per-launch HIP-event timing of the filter (up to 4096 launches per reset).

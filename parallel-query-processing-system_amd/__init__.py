@@ -212,6 +212,7 @@ def lib():
     L.pqps_ctx_destroy.argtypes = [vp]
     L.pqps_ctx_destroy.restype = None
     L.pqps_ctx_sync.argtypes = [vp, vp]
+    L.pqps_ctx_reserve.argtypes = [vp, u64]
     L.pqps_ctx_set_timing.argtypes = [vp, C.c_int]
     L.pqps_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.pqps_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(u64)]

@@ -220,6 +220,10 @@ __global__ void bump_codes_kernel(T *codes, uint64_t n, uint32_t threshold) {
     }
 }
 
+// Loads this library's code object (several MB, ~8 ms) when a context is created -- an engine does
+// that on a background thread beside its CSV parse -- instead of inside the first query.
+__global__ void warm_kernel() {}
+
 // ---- streaming read probe ----------------------------------------------------
 __global__ __launch_bounds__(256) void read_probe_kernel(const uint4 *p, uint64_t n16, uint64_t *out) {
     uint64_t acc = 0;
@@ -579,7 +583,31 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete ctx; return fail(PQPS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(1), 0, ctx->stream);
+    se = hipGetLastError();
+    if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);
+    if (se != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(PQPS_EHIP, "first kernel launch: %s", hipGetErrorString(se)); }
     *out = ctx;
+    return PQPS_OK;
+}
+
+int pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows) {
+    if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_scratch(ctx, (n_rows + kStepRows - 1) / kStepRows);
+    if (rc) return rc;
+    // the runtime's own fill / copy kernels are loaded on first use too (~5 ms): use them once here
+    HIP_TRY(hipMemsetAsync(ctx->base_slot, 0, 16, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->base_slot + 4, ctx->base_slot, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // ... and so are its staging buffers for copies to pageable host memory (an ID list download)
+    size_t warm = (size_t)ctx->scratch_steps * 64 * sizeof(uint16_t);
+    if (warm > ((size_t)8 << 20)) warm = (size_t)8 << 20;
+    if (void *host = malloc(warm)) {
+        hipError_t e = hipMemcpy(host, ctx->masks, warm, hipMemcpyDeviceToHost);
+        free(host);
+        if (e != hipSuccess) return fail(PQPS_EHIP, "staging warm-up: %s", hipGetErrorString(e));
+    }
     return PQPS_OK;
 }
 

@@ -420,6 +420,7 @@ static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *
     t->capacity_ids = t->capacity_rows;
     if (pqps_malloc(ctx, t->capacity_ids * sizeof(uint32_t), (void **)&t->ids_dev) != PQPS_OK) hip_die("result allocation");
     if (pqps_malloc(ctx, 8 * sizeof(uint64_t), (void **)&t->count_dev) != PQPS_OK) hip_die("counter allocation");
+    if (pqps_ctx_reserve(ctx, t->capacity_rows) != PQPS_OK) hip_die("filter scratch allocation");   /* not inside the first query */
     return t;
 }
 
