@@ -16,10 +16,10 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rocprim/device/device_radix_sort.hpp>   // index build only (stable LSD sort)
 
 #include "pqps_hip.h"
 #include "filter_kernels.hpp"
+#include "radix_sort.hpp"
 
 namespace {
 
@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256) void compact_index_slots_kernel(const uint32_t
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)gridDim.x * blockDim.x)
         if (displ + i < capacity) { ids_out[displ + i] = src[i]; keys_out[displ + i] = ksrc[i]; }
     if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0 && total_out) { total_out[0] = total; total_out[1] = raw; }
+}
+
+__global__ __launch_bounds__(256) void negate_iota_kernel(const uint32_t *ids, uint64_t n, uint32_t *neg, uint32_t *pos) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { neg[i] = ~ids[i]; pos[i] = (uint32_t)i; }
+}
+
+__global__ __launch_bounds__(256) void permute_pairs_kernel(const uint32_t *order, uint64_t n, const uint64_t *keys_in,
+                                                            const uint32_t *ids_in, uint64_t *keys_out, uint32_t *ids_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t p = order[i]; keys_out[i] = keys_in[p]; ids_out[i] = ids_in[p]; }
 }
 
 // ---- INSERT support: shift dictionary codes at or above a new value's rank -----------------
@@ -782,33 +793,32 @@ int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
 
 namespace {
 
-template <typename K>
+template <typename K, bool SIGNED>
 int index_build_t(pqps_ctx *ctx, const void *col, uint64_t n, uint32_t *perm, void *sorted_keys, hipStream_t s) {
     if (n == 0) return PQPS_OK;
     K *keys_rev = nullptr;
     uint32_t *rows_rev = nullptr;
+    pqps_sort::Workspace w;
     HIP_TRY(hipMalloc((void **)&keys_rev, n * sizeof(K)));
     hipError_t e = hipMalloc((void **)&rows_rev, n * sizeof(uint32_t));
-    if (e != hipSuccess) { (void)hipFree(keys_rev); return fail(PQPS_ENOMEM, "hipMalloc: %s", hipGetErrorString(e)); }
-    const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL((reverse_gather_kernel<K>), dim3(blocks), dim3(256), 0, s, (const K *)col, n, keys_rev, rows_rev);
-    size_t tmp_bytes = 0;
-    // stable LSD radix sort (rocPRIM): equal keys keep the descending-row input order
-    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_rev, (K *)sorted_keys, rows_rev, perm, n, 0, sizeof(K) * 8, s);
+    if (e == hipSuccess) e = pqps_sort::workspace_alloc(w, n);
+    bool in_a = true;
     if (e == hipSuccess) {
-        if (tmp_bytes > ctx->sort_tmp_bytes) {
-            if (ctx->sort_tmp) (void)hipFree(ctx->sort_tmp);
-            ctx->sort_tmp = nullptr; ctx->sort_tmp_bytes = 0;
-            e = hipMalloc(&ctx->sort_tmp, tmp_bytes);
-            if (e == hipSuccess) ctx->sort_tmp_bytes = tmp_bytes;
+        const uint32_t blocks = (uint32_t)((n + 255) / 256);
+        hipLaunchKernelGGL((reverse_gather_kernel<K>), dim3(blocks), dim3(256), 0, s, (const K *)col, n, keys_rev, rows_rev);
+        // stable LSD radix sort: equal keys keep the descending-row input order
+        e = pqps_sort::sort_pairs<K, SIGNED>(w, keys_rev, rows_rev, (K *)sorted_keys, perm, n, sizeof(K) * 8,
+                                             ctx->compute_units, s, &in_a);
+        if (e == hipSuccess && in_a) {                        // an even number of passes left the result in the scratch pair
+            e = hipMemcpyAsync(sorted_keys, keys_rev, n * sizeof(K), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(perm, rows_rev, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         }
-        if (e == hipSuccess)
-            e = rocprim::radix_sort_pairs(ctx->sort_tmp, tmp_bytes, keys_rev, (K *)sorted_keys, rows_rev, perm, n, 0, sizeof(K) * 8, s);
     }
     hipError_t e2 = hipStreamSynchronize(s);
     (void)hipFree(keys_rev);
     (void)hipFree(rows_rev);
-    if (e != hipSuccess) return fail(PQPS_EHIP, "radix_sort_pairs: %s", hipGetErrorString(e));
+    pqps_sort::workspace_free(w);
+    if (e != hipSuccess) return fail(PQPS_EHIP, "index sort: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) return fail(PQPS_EHIP, "index build sync: %s", hipGetErrorString(e2));
     return PQPS_OK;
 }
@@ -824,13 +834,13 @@ int pqps_index_build(pqps_ctx *ctx, const pqps_column *col, uint64_t n_rows, int
     hipStream_t s = pick_stream(ctx, stream);
     if (key_kind == 1) {
         if (col->width != 4) return fail(PQPS_EINVAL, "signed keys must be 4 bytes wide");
-        return index_build_t<int32_t>(ctx, col->data, n_rows, perm, sorted_keys, s);
+        return index_build_t<int32_t, true>(ctx, col->data, n_rows, perm, sorted_keys, s);
     }
     switch (col->width) {
-    case 1: return index_build_t<uint8_t>(ctx, col->data, n_rows, perm, sorted_keys, s);
-    case 2: return index_build_t<uint16_t>(ctx, col->data, n_rows, perm, sorted_keys, s);
-    case 4: return index_build_t<uint32_t>(ctx, col->data, n_rows, perm, sorted_keys, s);
-    case 8: return index_build_t<uint64_t>(ctx, col->data, n_rows, perm, sorted_keys, s);
+    case 1: return index_build_t<uint8_t, false>(ctx, col->data, n_rows, perm, sorted_keys, s);
+    case 2: return index_build_t<uint16_t, false>(ctx, col->data, n_rows, perm, sorted_keys, s);
+    case 4: return index_build_t<uint32_t, false>(ctx, col->data, n_rows, perm, sorted_keys, s);
+    case 8: return index_build_t<uint64_t, false>(ctx, col->data, n_rows, perm, sorted_keys, s);
     default: return fail(PQPS_EINVAL, "width %u not in {1,2,4,8}", col->width);
     }
 }
@@ -1033,15 +1043,32 @@ int pqps_merge_index_slots(pqps_ctx *ctx, const uint32_t *slots, const uint64_t 
     if (e == hipSuccess && host_totals[0] > merged_capacity)
         rc = fail(PQPS_EOVERFLOW, "merged capacity %llu too small for %llu IDs", (unsigned long long)merged_capacity, (unsigned long long)host_totals[0]);
     if (e == hipSuccess && rc == PQPS_OK && n > 0) {
-        // global leaf order = (key ascending, row descending): two stable passes, minor criterion first
-        size_t t1 = 0, t2 = 0;
-        e = rocprim::radix_sort_pairs_desc(nullptr, t1, ids_a, ids_b, keys_a, keys_b, n, 0, 32, s);
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, t2, keys_b, keys_a, ids_b, merged, n, 0, 64, s);
-        const size_t tb = t1 > t2 ? t1 : t2;
-        if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc(tmp, t1, ids_a, ids_b, keys_a, keys_b, n, 0, 32, s);
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, t2, keys_b, keys_a, ids_b, merged, n, 0, 64, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // global leaf order = (key ascending, row descending): two stable sorts, minor criterion first.
+        // pass 1 sorts by ~id (ascending ~id = descending id) carrying a permutation, pass 2 by key.
+        pqps_sort::Workspace w;
+        uint32_t *nid_a = nullptr, *nid_b = nullptr, *pos_a = nullptr, *pos_b = nullptr;
+        e = pqps_sort::workspace_alloc(w, n);
+        if (e == hipSuccess) e = hipMalloc((void **)&nid_a, n * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&nid_b, n * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&pos_a, n * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&pos_b, n * 4);
+        if (e == hipSuccess) {
+            const uint32_t blocks = (uint32_t)((n + 255) / 256);
+            hipLaunchKernelGGL(negate_iota_kernel, dim3(blocks), dim3(256), 0, s, ids_a, n, nid_a, pos_a);
+            bool in_a = true;
+            e = pqps_sort::sort_pairs<uint32_t, false>(w, nid_a, pos_a, nid_b, pos_b, n, 32, ctx->compute_units, s, &in_a);
+            const uint32_t *order = in_a ? pos_a : pos_b;         // positions of the compacted list, by descending id
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(permute_pairs_kernel, dim3(blocks), dim3(256), 0, s, order, n, keys_a, ids_a, keys_b, ids_b);
+                bool in_b = true;                                 // (keys_b, ids_b) is this sort's "a" pair
+                e = pqps_sort::sort_pairs<uint64_t, false>(w, keys_b, ids_b, keys_a, ids_a, n, 64, ctx->compute_units, s, &in_b);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(merged, in_b ? ids_b : ids_a, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+        }
+        (void)hipFree(nid_a); (void)hipFree(nid_b); (void)hipFree(pos_a); (void)hipFree(pos_b);
+        pqps_sort::workspace_free(w);
     }
     (void)hipFree(ids_a); (void)hipFree(ids_b); (void)hipFree(keys_a); (void)hipFree(keys_b); (void)hipFree(tmp);
     if (e != hipSuccess) return fail(PQPS_EHIP, "index slot merge: %s", hipGetErrorString(e));
