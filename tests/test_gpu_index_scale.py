@@ -75,6 +75,25 @@ def test_index_mode_matches_serial_semantics_5m(ctx):
         p = np.zeros(n, dtype=np.uint32)
         ctx.download(p.ctypes.data, d.perm, 4 * n)
         assert np.array_equal(p, perms[name].astype(np.uint32)), name
+    # 1- and 2-byte keys (BOOL / dictionary-coded STRING indexes), and a column with a single value
+    for name in ("sudo_used", "user_name", "host_name"):
+        d = DeviceIndex(ctx, dev, name, False)
+        p = np.zeros(n, dtype=np.uint32)
+        ctx.download(p.ctypes.data, d.perm, 4 * n)
+        assert np.array_equal(p, host_index_order(host.arr[name]).astype(np.uint32)), name
+        k = np.zeros(n, dtype=host.arr[name].dtype)
+        ctx.download(k.ctypes.data, d.keys, k.nbytes)
+        assert np.array_equal(k, np.sort(host.arr[name], kind="stable")), name
+        d.free()
+    const = pq.SyntheticTable(ctx, 70_001, seed=21, columns=["risk_level"])
+    L_ = pq.lib()
+    ctx.memset(const.ptr["risk_level"], 0, 4 * 70_001)           # every key equal: no pass runs, rows stay descending
+    d = DeviceIndex(ctx, const, "risk_level", True)
+    p = np.zeros(70_001, dtype=np.uint32)
+    ctx.download(p.ctypes.data, d.perm, 4 * 70_001)
+    assert np.array_equal(p, np.arange(70_000, -1, -1, dtype=np.uint32))
+    d.free()
+    const.free()
     out = ctx.malloc(4 * 3 * n)
     scratch = ctx.malloc(256)
     cases = [
