@@ -127,8 +127,8 @@ def cpu_baseline(pq, chain, sql, seed, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
     ap.add_argument("--query", default="S1", choices=sorted(QUERIES))
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
