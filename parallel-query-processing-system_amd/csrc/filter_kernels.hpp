@@ -607,9 +607,59 @@ struct RawStep {
         if constexpr (W2 != 0) eval_col_chain<W2, RPL, U, H>(a, 2, r2, acc);
         fold_half<MODE, H>(a, acc, cnt, mbits);
     }
+    // One comparison on one column (`sudo_used = TRUE`, `risk_level > 3`): all on the vector unit.  Each row
+    // slot is one compare plus one add-with-carry -- the compare's per-lane result enters `m + m + hit` (match
+    // bits, MSB first) or `total + hit` (COUNT) as the carry -- so a step costs ~35 VALU and next to no SALU.
+    // The ballot path above costs ~65 SALU per step even for one leaf, and a CU has ONE scalar unit: a 1-byte
+    // column needs a step per 79 cycles per CU to keep up with HBM, which the scalar unit cannot deliver.
+    template <int MODE, typename T, typename Hit>
+    __device__ __forceinline__ void one_leaf_rows(const T (&v)[16], Hit hit, uint32_t &m, uint32_t &lane_total) const {
+        if (MODE == MODE_IDS) {
+#pragma unroll
+            for (int r = 15; r >= 0; r--) m = m + m + (hit(v[r]) ? 1u : 0u);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) lane_total += hit(v[r]) ? 1u : 0u;
+        }
+    }
+    template <int MODE, typename T>
+    __device__ __forceinline__ void one_leaf(const EvalArgs &a, const T (&v)[16], uint32_t &m, uint32_t &lane_total) const {
+        const T lo = (T)a.lo[0], span = (T)a.span[0];
+        const bool want = ((a.chain_want & 1u) != 0) != (a.chain == 2);      // OR form of one leaf = its negation
+        if (span == 0) {                                                     // the six branches are wave-uniform
+            if (want) one_leaf_rows<MODE>(v, [lo](T x) { return x == lo; }, m, lane_total);
+            else one_leaf_rows<MODE>(v, [lo](T x) { return x != lo; }, m, lane_total);
+        } else if (lo == 0) {
+            if (want) one_leaf_rows<MODE>(v, [span](T x) { return x <= span; }, m, lane_total);
+            else one_leaf_rows<MODE>(v, [span](T x) { return x > span; }, m, lane_total);
+        } else {
+            if (want) one_leaf_rows<MODE>(v, [lo, span](T x) { return (T)(x - lo) <= span; }, m, lane_total);
+            else one_leaf_rows<MODE>(v, [lo, span](T x) { return (T)(x - lo) > span; }, m, lane_total);
+        }
+    }
     template <int MODE>
     __device__ __forceinline__ void eval_chain_emit(const EvalArgs &a, uint64_t step, uint32_t rpl_log2, uint32_t lane,
-                                                    uint64_t &wave_total) const {
+                                                    uint64_t &wave_total, uint32_t &lane_total) const {
+        if constexpr (W1 == 0) {
+            if (a.n_leaves == 1) {                                           // uniform
+                uint32_t m = 0;
+                if constexpr (W0 == 8) {
+                    uint64_t v[16];
+                    unpack64(r0, v, std::make_integer_sequence<int, 16>{});
+                    one_leaf<MODE, uint64_t>(a, v, m, lane_total);
+                } else {
+                    uint32_t v[16];
+                    unpack32(r0, v, std::make_integer_sequence<int, 16>{});
+                    one_leaf<MODE, uint32_t>(a, v, m, lane_total);
+                }
+                if (MODE == MODE_IDS) {
+                    const uint32_t cnt = wave_sum_u32(__popc(m));
+                    if (cnt) store_mask(a, step, m, lane);
+                    if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
+                }
+                return;
+            }
+        }
         uint32_t cnt = 0, mbits = 0;
         eval_chain_half<MODE, 0>(a, cnt, mbits);
         eval_chain_half<MODE, 1>(a, cnt, mbits);
@@ -685,6 +735,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
     uint64_t wave_total = 0;
+    uint32_t lane_total = 0;                                    // COUNT, one-leaf path: per-lane matches, summed once at the end
     RawStep<W0, W1, W2, RPL, U> A[S];
     for (uint64_t step0 = wave; step0 < full_steps; step0 += n_waves * S) {
 #pragma unroll
@@ -696,13 +747,14 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i * n_waves;
             if (step >= full_steps) break;
-            A[i].template eval_chain_emit<MODE>(a, step, log2i(RPL), lane, wave_total);
+            A[i].template eval_chain_emit<MODE>(a, step, log2i(RPL), lane, wave_total, lane_total);
         }
     }
     if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
         const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
         emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
     }
+    if (MODE != MODE_IDS) wave_total += wave_sum_u32(lane_total);
     clear_super_sums<MODE>(a);
     finish_totals<MODE>(a, wave_total);
 }
