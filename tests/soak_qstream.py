@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test of the query stream: thousands of queries of mixed shapes back to back through
-pqps_qstream_scan, every result compared with the oracle's.  usage: scripts/soak_qstream.py [queries]"""
+pqps_qstream_scan, every result compared with the oracle's.  usage: python tests/soak_qstream.py [queries]   (manual; not collected by pytest)"""
 import ctypes as C
 import pathlib
 import random
@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests"))       # the oracle is the checker here, as in the test suite
 import qpelib as q  # noqa: E402
 
 pq = q.pq
