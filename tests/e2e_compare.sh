@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-to-end: the real reference driver (oracle/_ref/QPESeq_ref) vs QPEHIP on the same synthetic CSV and
-# the reference's sample-queries.txt (QUERIES=sample-queries-FULL.txt for the file with the DELETE).  usage: scripts/e2e_compare.sh <rows>
+# the reference's sample-queries.txt (QUERIES=sample-queries-FULL.txt for the file with the DELETE).  usage: tests/e2e_compare.sh <rows>
 rows=${1:-1000000}
 work=$(mktemp -d)
 python3 $GRAFT_REPO_ROOT/scripts/make_csv.py $rows $work/data.csv
