@@ -55,6 +55,7 @@ struct EvalArgs {
     uint32_t negmask;
     uint32_t streaming;              // host side only: the scan outgrows the Infinity Cache (grid + load policy)
     uint32_t steps_per_iter;         // host side only: S of the chosen kernel (grid sizing)
+    uint32_t valu_chain;             // host side only: the one-leaf vector-unit kernel variant was chosen
     uint32_t chain;                  // 0: general tree; 1: AND of leaves; 2: NOT(AND) = OR form (spec kernels)
     uint32_t chain_want;             // bit k: raw window hit that leaf slot k must have inside the AND
     uint32_t pad0;
@@ -637,33 +638,35 @@ struct RawStep {
             else one_leaf_rows<MODE>(v, [lo, span](T x) { return (T)(x - lo) > span; }, m, lane_total);
         }
     }
-    template <int MODE>
+    // VC: the vector-unit variant for ONE comparison on ONE column -- a kernel of its own, so that its registers
+    // do not weigh on the ballot path's occupancy.  (The same idea for chains of two or three leaves was
+    // measured too: no gain -- with 3+ bytes per row the scalar unit is not what limits the scan.)
+    template <int MODE, bool VC>
     __device__ __forceinline__ void eval_chain_emit(const EvalArgs &a, uint64_t step, uint32_t rpl_log2, uint32_t lane,
                                                     uint64_t &wave_total, uint32_t &lane_total) const {
-        if constexpr (W1 == 0) {
-            if (a.n_leaves == 1) {                                           // uniform
-                uint32_t m = 0;
-                if constexpr (W0 == 8) {
-                    uint64_t v[16];
-                    unpack64(r0, v, std::make_integer_sequence<int, 16>{});
-                    one_leaf<MODE, uint64_t>(a, v, m, lane_total);
-                } else {
-                    uint32_t v[16];
-                    unpack32(r0, v, std::make_integer_sequence<int, 16>{});
-                    one_leaf<MODE, uint32_t>(a, v, m, lane_total);
-                }
-                if (MODE == MODE_IDS) {
-                    const uint32_t cnt = wave_sum_u32(__popc(m));
-                    if (cnt) store_mask(a, step, m, lane);
-                    if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
-                }
-                return;
+        if constexpr (VC) {
+            static_assert(W1 == 0 && W2 == 0, "one column");
+            uint32_t m = 0;
+            if constexpr (W0 == 8) {
+                uint64_t v[16];
+                unpack64(r0, v, std::make_integer_sequence<int, 16>{});
+                one_leaf<MODE, uint64_t>(a, v, m, lane_total);
+            } else {
+                uint32_t v[16];
+                unpack32(r0, v, std::make_integer_sequence<int, 16>{});
+                one_leaf<MODE, uint32_t>(a, v, m, lane_total);
             }
+            if (MODE == MODE_IDS) {
+                const uint32_t cnt = wave_sum_u32(__popc(m));
+                if (cnt) store_mask(a, step, m, lane);
+                if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
+            }
+        } else {
+            uint32_t cnt = 0, mbits = 0;
+            eval_chain_half<MODE, 0>(a, cnt, mbits);
+            eval_chain_half<MODE, 1>(a, cnt, mbits);
+            emit_chain_step<MODE>(a, step, cnt, mbits, rpl_log2, lane, wave_total);
         }
-        uint32_t cnt = 0, mbits = 0;
-        eval_chain_half<MODE, 0>(a, cnt, mbits);
-        eval_chain_half<MODE, 1>(a, cnt, mbits);
-        emit_chain_step<MODE>(a, step, cnt, mbits, rpl_log2, lane, wave_total);
     }
     __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {     // <= 6 leaves: row-mask path
         LeafMasks lm;
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
 // from 2 bytes per row on S = 1 is as good or better (u16 0.72 / 0.82 vs 0.72 / 0.80; u16+u8 0.71 vs 0.69).
 constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 4 : 1; }
 
-template <int MODE, int W0, int W1, int W2, int S, bool NT>
+template <int MODE, int W0, int W1, int W2, int S, bool NT, bool VC>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i * n_waves;
             if (step >= full_steps) break;
-            A[i].template eval_chain_emit<MODE>(a, step, log2i(RPL), lane, wave_total, lane_total);
+            A[i].template eval_chain_emit<MODE, VC>(a, step, log2i(RPL), lane, wave_total, lane_total);
         }
     }
     if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {

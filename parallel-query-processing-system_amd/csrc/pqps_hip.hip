@@ -409,10 +409,19 @@ typedef void (*eval_fn)(const EvalArgs);
     X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
 
 // chain kernels exist with 1 step per iteration and (narrow shapes) with several
+// the vector-unit variant (VC) exists for the single-column shapes only
+template <int MODE, int A, int B, int C, int S, bool NT>
+eval_fn chain_variant(bool vc) {
+    if constexpr (B == 0 && C == 0) {
+        if (vc) return eval_chain_kernel<MODE, A, B, C, S, NT, true>;
+    }
+    return eval_chain_kernel<MODE, A, B, C, S, NT, false>;
+}
+
 template <int MODE, bool NT>
-eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step) {
+eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool vc) {
 #define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return !chain ? eval_spec_kernel<MODE, A, B, C, NT> \
-        : (multi_step ? eval_chain_kernel<MODE, A, B, C, chain_steps(A, B, C), NT> : eval_chain_kernel<MODE, A, B, C, 1, NT>);
+        : (multi_step ? chain_variant<MODE, A, B, C, chain_steps(A, B, C), NT>(vc) : chain_variant<MODE, A, B, C, 1, NT>(vc));
     PQPS_FOR_EACH_SHAPE(X)
 #undef X
     return nullptr;
@@ -435,8 +444,8 @@ void set_streaming(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, uint64
 }
 
 template <int MODE>
-eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool nt) {
-    return nt ? find_spec_nt<MODE, true>(w0, w1, w2, chain, multi_step) : find_spec_nt<MODE, false>(w0, w1, w2, chain, multi_step);
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool nt, bool vc) {
+    return nt ? find_spec_nt<MODE, true>(w0, w1, w2, chain, multi_step, vc) : find_spec_nt<MODE, false>(w0, w1, w2, chain, multi_step, vc);
 }
 
 // `a` must already carry the chain classification of fill_args(); sets a.streaming.
@@ -448,7 +457,10 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
         // several steps per iteration only where chain_steps() says so (a lone 1-byte column)
         static const char *force = getenv("PQPS_CHAIN_MULTI");
         const bool multi = force ? atoi(force) != 0 : true;
-        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, a.streaming != 0)) {   // nullptr unless widths are non-increasing
+        // one comparison on one column: the vector-unit kernel variant (see RawStep::one_leaf)
+        const bool vc = a.chain != 0 && pred->n_leaves == 1 && n_cols == 1;
+        a.valu_chain = vc ? 1u : 0u;
+        if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, a.streaming != 0, vc)) {   // nullptr unless widths are non-increasing
             if (a.chain != 0 && multi) a.steps_per_iter = (uint32_t)chain_steps((int)w0, (int)w1, (int)w2);
             return f;
         }
