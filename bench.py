@@ -363,7 +363,7 @@ def main():
 RING = 4      # result slots in flight: query k's merge runs under the scans of queries k+1 ..
 
 # the K1 instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
-K1_NAMES = {"S1": "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT = scan footprint > 320 MiB>"}
+K1_NAMES = {"S1": "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT = scan footprint > 320 MiB, VC=false>"}
 
 
 def pmc_traffic(query, rows):
