@@ -472,6 +472,34 @@ def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log)
                                "rows_per_s_table": count / (ms * 1e-3)}
         log(f"index {label}: build {build_ms:.1f} ms, probe+filter {ms * 1e3:.0f} us, slice {slice_len:,}, {matches:,} matches")
         del perm, keys
+    # ---- projection on the device: the selected columns of the result rows, gathered by ID ----
+    if "Q_A" in names and {"command_id", "user_id", "risk_level"} <= have:
+        chain, sql = QUERIES["Q_A"]
+        pred, cols, nc, bpr = table.bind(chain)
+        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), ids.data_ptr(), count, cnt.data_ptr(), sptr))
+        torch.cuda.synchronize()
+        matches = int(cnt[0].item())
+        proj_cols = ["command_id", "user_id", "risk_level"]
+        outs = [torch.empty(max(matches, 1) * table.width[c], dtype=torch.uint8, device=device) for c in proj_cols]
+        carrs = [pq.column_array([(table.ptr[c], table.width[c])]) for c in proj_cols]
+
+        def project():
+            for c, carr, o in zip(proj_cols, carrs, outs):
+                pq.check(L.pqps_project_column(ctx.h, carr, ids.data_ptr(), cnt.data_ptr(), matches, start, o.data_ptr(), sptr), "pqps_project_column")
+        for _ in range(3):
+            project()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            project()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out_bytes = matches * sum(table.width[c] for c in proj_cols)
+        out["Q_A_project_3_columns"] = {"query": sql, "columns": proj_cols, "rows": matches, "ms": ms,
+                                        "rows_per_s": matches / (ms * 1e-3), "output_GBps": out_bytes / (ms * 1e-3) / 1e9}
+        log(f"projection of {proj_cols} for {matches:,} result rows: {ms * 1e3:.0f} us")
+        del outs
     # PCIe-inclusive, one blocking query at a time (what a host caller of the shim sees): scan, wait,
     # read the count back, download the IDs into host memory.  Never `value`.
     import numpy as np

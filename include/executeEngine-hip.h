@@ -64,6 +64,34 @@ long long executeQuerySelectIdsHIP(struct engineS *engine,
                                    struct whereClauseS *whereClause,
                                    unsigned int **ids, double *queryTime);
 
+/* Columnar SELECT: the scalable form of resultSetS (executeEngine-serial.h:30-38, whose rows x columns
+ * heap strings are the right shape for 50 k rows, not for 10^8).  Same row selection and order as
+ * executeQuerySelectHIP; the selected columns are gathered ON THE DEVICE for the result rows
+ * (pqps_project_column) and come back as typed arrays; text exists only for the cells someone asks for
+ * (hipColumnarCellText, hipColumnarHead -> printTable), formatted exactly as get_attribute_string_value
+ * (serial:216-248) would. */
+struct hipColumnarResult {
+    int numRecords;
+    int numColumns;
+    char **columnNames;
+    int *columnKinds;                  /* HIPKIND_U64 / _I32 / _BOOL / _DICT (hipPredicate.h); -1 = unknown column ("NULL" cells) */
+    void **values;                     /* per column, numRecords entries: uint64_t / int32_t / uint8_t / uint32_t dictionary code */
+    const char *const **dictionaries;  /* per column: code -> C string for _DICT columns (owned by the engine: valid until it is
+                                          modified by INSERT / DELETE or destroyed), else NULL */
+    double queryTime;                  /* selection + device gather + download */
+    bool success;
+};
+struct hipColumnarResult *executeQuerySelectColumnarHIP(struct engineS *engine, const char **selectItems, int numSelectItems,
+                                                        struct whereClauseS *whereClause);
+void freeColumnarResultHIP(struct hipColumnarResult *result);
+/* malloc'd text of one cell. */
+char *hipColumnarCellText(const struct hipColumnarResult *result, int row, int column);
+/* The first `limit` rows (all if limit <= 0, printTable's own convention) as an ordinary result set, e.g. for printTable; numRecords of the
+ * returned set is the FULL count, as printTable's footer reports it, and only `limit` rows of data exist --
+ * free it with freeResultSetHead. */
+struct resultSetS *hipColumnarHead(const struct hipColumnarResult *result, int limit);
+void freeResultSetHead(struct resultSetS *head, int rows);
+
 /* COUNT(*) through the backend API (the reference parser cannot express it,
  * SURVEY.md fact 10): scan-mode count of matching rows, no ID list. */
 long long executeQueryCountHIP(struct engineS *engine, struct whereClauseS *whereClause);

@@ -181,6 +181,13 @@ int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int
 int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                       const uint8_t *delete_flags, uint64_t *kept_out, void *stream);
 
+/* Projection on the device (the gather half of executeEngine-serial.c:504-515): out[i] = the column's
+ * value (numeric, or the dictionary code of a string column) of result row ids[i], for the first
+ * min(*count_dev, capacity) rows; `out` has the column's width.  Works for any ID order (scan or index
+ * mode).  A caller that wants text materialises it from these values only for the rows it shows. */
+int pqps_project_column(pqps_ctx *ctx, const pqps_column *col, const uint32_t *ids, const uint64_t *count_dev,
+                        uint64_t capacity, uint32_t id_base, void *out, void *stream);
+
 /* Index mode across shards (no counterpart in the reference: its MPI engine replicates the table).
  * A shard's index-mode result is ordered (key asc, row desc) within the shard; rows of a higher rank
  * are higher rows, so the table-wide leaf order of engine/bplus.c:282-358 is the sort of the union by

@@ -86,6 +86,13 @@ class ResultSet(C.Structure):
     ]
 
 
+class ColumnarResult(C.Structure):
+    """struct hipColumnarResult (include/executeEngine-hip.h)."""
+    _fields_ = [("numRecords", C.c_int), ("numColumns", C.c_int), ("columnNames", C.POINTER(C.c_char_p)),
+                ("columnKinds", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_void_p)),
+                ("dictionaries", C.POINTER(C.POINTER(C.c_char_p))), ("queryTime", C.c_double), ("success", C.c_bool)]
+
+
 class EngineS(C.Structure):
     _fields_ = [
         ("tableName", C.c_char_p),
@@ -237,6 +244,7 @@ def lib():
     L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
     L.pqps_bump_codes.argtypes = [vp, vp, u32, u64, u32, vp]
     L.pqps_compact_rows.argtypes = [vp, C.POINTER(Column), u32, u64, vp, C.POINTER(u64), vp]
+    L.pqps_project_column.argtypes = [vp, C.POINTER(Column), vp, vp, u64, u32, vp, vp]
     L.pqps_gather_keys.argtypes = [vp, C.POINTER(Column), C.c_int, vp, vp, u64, u32, vp, vp]
     L.pqps_merge_index_slots.argtypes = [vp, vp, vp, u32, u64, vp, u64, vp, vp]
     L.pqps_merge_slots.argtypes = [vp, vp, u32, u64, vp, u64, vp, vp]
@@ -269,6 +277,15 @@ def lib():
     L.executeQuerySelectIdsHIP.argtypes = [E, W, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_double)]
     L.executeQueryCountHIP.restype = C.c_longlong
     L.executeQueryCountHIP.argtypes = [E, W]
+    CR = C.POINTER(ColumnarResult)
+    L.executeQuerySelectColumnarHIP.restype = CR
+    L.executeQuerySelectColumnarHIP.argtypes = [E, C.POINTER(C.c_char_p), C.c_int, W]
+    L.freeColumnarResultHIP.argtypes = [CR]
+    L.hipColumnarCellText.restype = vp
+    L.hipColumnarCellText.argtypes = [CR, C.c_int, C.c_int]
+    L.hipColumnarHead.restype = C.POINTER(ResultSet)
+    L.hipColumnarHead.argtypes = [CR, C.c_int]
+    L.freeResultSetHead.argtypes = [C.POINTER(ResultSet), C.c_int]
     L.executeQueryDeleteHIP.restype = C.POINTER(ResultSet)
     L.executeQueryDeleteHIP.argtypes = [E, C.c_char_p, W]
     L.executeQueryInsertHIP.restype = C.c_bool
@@ -504,6 +521,41 @@ class HipEngine:
                    success=bool(r.success), queryTime=r.queryTime)
         lib().freeResultSet(rs)
         return out
+
+    def select_columnar(self, columns, chain, text=True):
+        """executeQuerySelectColumnarHIP: typed per-column arrays gathered on the device; with text=True
+        also every cell as the string hipColumnarCellText makes of it."""
+        import numpy as np
+        L = lib()
+        wl = WhereList(chain)
+        items = (C.c_char_p * max(1, len(columns or [])))(*[c.encode() for c in (columns or [])])
+        res = L.executeQuerySelectColumnarHIP(self.e, items if columns else None, len(columns or []), wl.ptr)
+        r = res.contents
+        n, m = r.numRecords, r.numColumns
+        dtypes = {0: np.uint64, 1: np.int32, 2: np.uint8, 3: np.uint32}
+        out = dict(numRecords=n, numColumns=m, columns=[r.columnNames[j].decode() for j in range(m)],
+                   kinds=[r.columnKinds[j] for j in range(m)], values=[], success=bool(r.success), handle=res)
+        for j in range(m):
+            k = r.columnKinds[j]
+            if k < 0 or n == 0 or not r.values[j]:
+                out["values"].append(None)
+            else:
+                dt = np.dtype(dtypes[k])
+                out["values"].append(np.frombuffer(C.string_at(r.values[j], n * dt.itemsize), dtype=dt).copy())
+        if text:
+            rows = []
+            for i in range(n):
+                row = []
+                for j in range(m):
+                    p = L.hipColumnarCellText(res, i, j)
+                    row.append(C.string_at(p).decode("latin-1"))
+                    L.free(p)
+                rows.append(row)
+            out["rows"] = rows
+        return out
+
+    def free_columnar(self, out):
+        lib().freeColumnarResultHIP(out.pop("handle"))
 
     def record(self, i):
         return self.e.contents.all_records[i].contents

@@ -188,6 +188,16 @@ __global__ __launch_bounds__(256) void gather_keys_kernel(const T *__restrict__ 
     }
 }
 
+// projection: out[i] = col[ids[i] - id_base] for the result list of a query (count read on the device)
+template <typename T>
+__global__ __launch_bounds__(256) void project_kernel(const T *__restrict__ col, const uint32_t *__restrict__ ids,
+                                                      const uint64_t *count, uint64_t capacity, uint32_t id_base, T *__restrict__ out) {
+    uint64_t n = *count;
+    if (n > capacity) n = capacity;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = col[ids[i] - id_base];
+}
+
 // rank-order compaction of [count | ids] slots together with their parallel key slots
 __global__ __launch_bounds__(256) void compact_index_slots_kernel(const uint32_t *slots, const uint64_t *key_slots, uint32_t world,
                                                                   uint64_t slot_stride, uint32_t *ids_out, uint64_t *keys_out,
@@ -1002,6 +1012,25 @@ int pqps_compact_rows(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, u
     (void)hipFree(keep); (void)hipFree(count_dev); (void)hipFree(tmp);
     if (!rc) *kept_out = kept;
     return rc;
+}
+
+int pqps_project_column(pqps_ctx *ctx, const pqps_column *col, const uint32_t *ids, const uint64_t *count_dev,
+                        uint64_t capacity, uint32_t id_base, void *out, void *stream) {
+    if (!ctx || !col || !col->data || !ids || !count_dev || !out) return fail(PQPS_EINVAL, "NULL argument");
+    hipStream_t s = pick_stream(ctx, stream);
+    uint64_t blocks = (capacity + 255) / 256;
+    if (blocks > (uint64_t)ctx->compute_units * 16) blocks = (uint64_t)ctx->compute_units * 16;
+    if (blocks == 0) blocks = 1;
+    const dim3 g((uint32_t)blocks), b(256);
+    switch (col->width) {
+    case 1: hipLaunchKernelGGL((project_kernel<uint8_t>), g, b, 0, s, (const uint8_t *)col->data, ids, count_dev, capacity, id_base, (uint8_t *)out); break;
+    case 2: hipLaunchKernelGGL((project_kernel<uint16_t>), g, b, 0, s, (const uint16_t *)col->data, ids, count_dev, capacity, id_base, (uint16_t *)out); break;
+    case 4: hipLaunchKernelGGL((project_kernel<uint32_t>), g, b, 0, s, (const uint32_t *)col->data, ids, count_dev, capacity, id_base, (uint32_t *)out); break;
+    case 8: hipLaunchKernelGGL((project_kernel<uint64_t>), g, b, 0, s, (const uint64_t *)col->data, ids, count_dev, capacity, id_base, (uint64_t *)out); break;
+    default: return fail(PQPS_EINVAL, "width %u not in {1,2,4,8}", col->width);
+    }
+    HIP_TRY(hipGetLastError());
+    return PQPS_OK;
 }
 
 int pqps_gather_keys(pqps_ctx *ctx, const pqps_column *col, int key_kind, const uint32_t *ids, const uint64_t *count_dev,

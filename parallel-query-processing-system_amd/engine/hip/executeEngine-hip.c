@@ -274,6 +274,112 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
     return rs;
 }
 
+/* ---- columnar SELECT ------------------------------------------------------------------------------- */
+
+struct hipColumnarResult *executeQuerySelectColumnarHIP(struct engineS *engine, const char **selectItems, int numSelectItems,
+                                                        struct whereClauseS *whereClause) {
+    struct hipColumnarResult *res = calloc(1, sizeof *res);
+    if (!res) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+    if (!engine || !engine->record_block) return res;
+    struct hipTable *t = engine->record_block;
+    if (selectItems == NULL || numSelectItems == 0) { selectItems = (const char **)k_all_columns; numSelectItems = 12; }
+    res->numColumns = numSelectItems;
+    res->columnNames = calloc((size_t)numSelectItems, sizeof(char *));
+    res->columnKinds = calloc((size_t)numSelectItems, sizeof(int));
+    res->values = calloc((size_t)numSelectItems, sizeof(void *));
+    res->dictionaries = calloc((size_t)numSelectItems, sizeof(*res->dictionaries));
+    if (!res->columnNames || !res->columnKinds || !res->values || !res->dictionaries) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+
+    const double t0 = now_seconds();
+    hipTableLockShared(t);
+    hipTableLockDevice(t);
+    const uint64_t count = run_selection(engine, t, whereClause);      /* IDs stay in t->ids_dev, the count in t->count_dev */
+    struct hipSchema schema;
+    hipSchemaOfTable(t, &schema);
+    void *gathered = NULL;
+    if (count) SHIM(pqps_malloc(t->ctx, count * 8, &gathered), "projection buffer");
+    for (int j = 0; j < numSelectItems; j++) {
+        res->columnNames[j] = strdup(selectItems[j]);
+        const int c = hipColumnId(selectItems[j]);
+        res->columnKinds[j] = c < 0 ? -1 : schema.col[c].kind;
+        if (c < 0 || count == 0) continue;
+        const uint32_t w = t->col[c].width;
+        SHIM(pqps_project_column(t->ctx, &t->col[c], t->ids_dev, t->count_dev, count, 0, gathered, NULL), "device projection");
+        void *raw = malloc(count * w);
+        if (!raw) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+        SHIM(pqps_download(t->ctx, raw, gathered, count * w, NULL), "projection download");
+        if (schema.col[c].kind == HIPKIND_DICT) {                       /* codes are widened to u32 whatever the column stores */
+            res->dictionaries[j] = schema.col[c].dict;
+            if (w != 4) {
+                uint32_t *wide = malloc(count * sizeof *wide);
+                if (!wide) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+                if (w == 1) for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint8_t *)raw)[i];
+                else for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint16_t *)raw)[i];
+                free(raw);
+                raw = wide;
+            }
+        }
+        res->values[j] = raw;
+    }
+    if (gathered) pqps_free(t->ctx, gathered);
+    hipTableUnlockDevice(t);
+    hipTableUnlock(t);
+    res->numRecords = (int)count;
+    res->queryTime = now_seconds() - t0;
+    res->success = true;
+    TRACE("SELECT (columnar): %d rows x %d columns in %.3f ms\n", res->numRecords, res->numColumns, res->queryTime * 1e3);
+    return res;
+}
+
+void freeColumnarResultHIP(struct hipColumnarResult *res) {
+    if (!res) return;
+    for (int j = 0; j < res->numColumns; j++) {
+        if (res->columnNames) free(res->columnNames[j]);
+        if (res->values) free(res->values[j]);
+    }
+    free(res->columnNames); free(res->columnKinds); free(res->values); free((void *)res->dictionaries);
+    free(res);
+}
+
+char *hipColumnarCellText(const struct hipColumnarResult *res, int row, int col) {
+    char buf[32];
+    if (!res || row < 0 || row >= res->numRecords || col < 0 || col >= res->numColumns) return NULL;
+    const void *v = res->values[col];
+    switch (res->columnKinds[col]) {                                    /* get_attribute_string_value, S:216-248 */
+    case HIPKIND_U64: snprintf(buf, sizeof buf, "%llu", (unsigned long long)((const uint64_t *)v)[row]); return strdup(buf);
+    case HIPKIND_I32: snprintf(buf, sizeof buf, "%d", ((const int32_t *)v)[row]); return strdup(buf);
+    case HIPKIND_BOOL: return strdup(((const uint8_t *)v)[row] ? "true" : "false");
+    case HIPKIND_DICT: return strdup(res->dictionaries[col][((const uint32_t *)v)[row]]);
+    default: return strdup("NULL");                                     /* unknown column, S:244 */
+    }
+}
+
+struct resultSetS *hipColumnarHead(const struct hipColumnarResult *res, int limit) {
+    struct resultSetS *rs = calloc(1, sizeof *rs);
+    if (!rs || !res) { free(rs); return NULL; }
+    const int rows = limit <= 0 || limit > res->numRecords ? res->numRecords : limit;   /* printTable: limit <= 0 = every row */
+    rs->numRecords = res->numRecords;                                   /* the footer counts every record */
+    rs->numColumns = res->numColumns;
+    rs->columnNames = malloc((size_t)(res->numColumns > 0 ? res->numColumns : 1) * sizeof(char *));
+    for (int j = 0; j < res->numColumns; j++) rs->columnNames[j] = strdup(res->columnNames[j]);
+    rs->columnTypes = calloc((size_t)(res->numColumns > 0 ? res->numColumns : 1), sizeof(FieldType));
+    rs->data = malloc((size_t)(rows > 0 ? rows : 1) * sizeof(char **));
+    for (int i = 0; i < rows; i++) {
+        rs->data[i] = malloc((size_t)(res->numColumns > 0 ? res->numColumns : 1) * sizeof(char *));
+        for (int j = 0; j < res->numColumns; j++) rs->data[i][j] = hipColumnarCellText(res, i, j);
+    }
+    rs->queryTime = res->queryTime;
+    rs->success = res->success;
+    return rs;
+}
+
+void freeResultSetHead(struct resultSetS *head, int rows) {
+    if (!head) return;
+    const int full = head->numRecords;
+    head->numRecords = rows <= 0 || rows > full ? full : rows;          /* only these rows were materialised */
+    freeResultSet(head);
+}
+
 /* freeResultSet, S:881-908. */
 void freeResultSet(struct resultSetS *result) {
     if (!result) return;

@@ -141,6 +141,52 @@ def test_insert_then_delete_roundtrip(tmp_path):
     eng.close()
 
 
+def test_columnar_select_equals_the_string_result_set():
+    """executeQuerySelectColumnarHIP (device-gathered typed columns) against executeQuerySelectHIP on golden
+    queries: same rows in the same order (scan and index mode, SELECT *, unknown columns), every cell's text
+    identical; hipColumnarHead + printTable prints what the reference printed (print_golden.json)."""
+    import tempfile
+    L = pq.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    eng = pq.HipEngine(q.GOLDEN / "commands_2k.csv", pq.DEFAULT_INDEXES)
+    cases = [(None, [("risk_level", "=", "5")]),
+             (["command_id", "raw_command", "user_name", "risk_level", "timestamp"], [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")]),
+             (["bogus", "command_id", "sudo_used", "exit_code"], [("risk_level", ">", "3")]),
+             (["user_name", "working_directory", "base_command", "host_name", "shell_type"],
+              [("user_id", "=", "1001"), "OR", [("user_name", "=", "student1002"), "AND", ("shell_type", "=", "zsh")]]),
+             (["command_id"], [("risk_level", ">", "9")]),
+             (None, [])]
+    for cols, chain in cases:
+        want = eng.select(cols, chain)
+        got = eng.select_columnar(cols, chain)
+        assert got["success"] and got["numRecords"] == want["numRecords"] and got["columns"] == want["columns"]
+        assert got["rows"] == want["rows"], (cols, chain)
+        eng.free_columnar(got)
+    gold = json.loads((q.GOLDEN / "print_golden.json").read_text())
+    for case in gold:
+        if case["indexes"] != "default":
+            continue
+        sql = case["sql"]
+        sel = sql[len("SELECT "):sql.index(" FROM ")]
+        cols = None if sel.strip() == "*" else [c.strip() for c in sel.split(",")]
+        chain = q.parse_where_dump(q.call_text(L.hipDumpParse, sql.encode()).split(q.RS, 1)[1])
+        got = eng.select_columnar(cols, chain, text=False)
+        got["handle"].contents.queryTime = 0.0
+        head = L.hipColumnarHead(got["handle"], case["limit"])
+        with tempfile.NamedTemporaryFile(suffix=".txt") as tf:
+            f = libc.fopen(tf.name.encode(), b"w")
+            L.printTable(f, head, case["limit"])
+            libc.fclose(f)
+            text = open(tf.name, encoding="latin-1").read()
+        L.freeResultSetHead(head, case["limit"])
+        eng.free_columnar(got)
+        assert text == case["text"], case["name"]
+    eng.close()
+
+
 def test_engine_is_safe_under_concurrent_callers(tmp_path):
     """The reference's OpenMP driver calls one engine from several threads (QPEOMP.c:234-291).
     8 reader threads (scan mode, index mode, COUNT, projection) run against a writer that keeps
