@@ -721,10 +721,12 @@ __global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
 // Chain predicates (AND of possibly complemented leaves, or the negation of one): SGPR planes.
 // A wave keeps the loads of S steps in flight (all S x columns loads are issued, then the steps
 // are evaluated one after the other).
-// Measured with streaming loads (1 B rows / 100 M rows, fraction of 8 TB/s): a lone 1-byte column needs
-// S = 4 (0.70 / 0.57 against 0.48 / 0.56 with S = 1: 1 KB per wave and step is too little in flight);
-// from 2 bytes per row on S = 1 is as good or better (u16 0.72 / 0.82 vs 0.72 / 0.80; u16+u8 0.71 vs 0.69).
-constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 4 : 1; }
+// Steps per loop iteration (adjacent steps, so the chip-wide access window stays one contiguous range).
+// Measured, fraction of 8 TB/s at 100 M / 1 B rows: a lone 1-byte column wants 2 (COUNT 0.71 / 0.86, IDs
+// 0.61 / 0.69; 1 step: 0.56 / 0.48; 4: 0.72 / 0.86 and 0.60 / 0.65; 8: worse) -- 1 KB per wave and step is
+// too little in flight; from 2 bytes per row on, 1 is best (u16+u8: 0.83 / 0.82 against 0.80 / 0.82 with 2
+// and 0.77 / 0.80 with 4).
+constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 2 : 1; }
 
 template <int MODE, int W0, int W1, int W2, int S, bool NT, bool VC>
 __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
@@ -740,15 +742,16 @@ __global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
     uint64_t wave_total = 0;
     uint32_t lane_total = 0;                                    // COUNT, one-leaf path: per-lane matches, summed once at the end
     RawStep<W0, W1, W2, RPL, U> A[S];
-    for (uint64_t step0 = wave; step0 < full_steps; step0 += n_waves * S) {
+    // a wave takes S ADJACENT steps per iteration: the chip-wide access window stays one contiguous range
+    for (uint64_t step0 = wave * S; step0 < full_steps; step0 += n_waves * S) {
 #pragma unroll
         for (int i = 0; i < S; i++) {
-            const uint64_t step = step0 + (uint64_t)i * n_waves;
+            const uint64_t step = step0 + (uint64_t)i;
             if (step < full_steps) A[i].template load<NT>(a, step * kStepRows + lane_off);      // uniform guard
         }
 #pragma unroll
         for (int i = 0; i < S; i++) {
-            const uint64_t step = step0 + (uint64_t)i * n_waves;
+            const uint64_t step = step0 + (uint64_t)i;
             if (step >= full_steps) break;
             A[i].template eval_chain_emit<MODE, VC>(a, step, log2i(RPL), lane, wave_total, lane_total);
         }
