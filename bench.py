@@ -343,10 +343,19 @@ def main():
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
     }
 
+    # side measurements must never cost the headline line
     if rank == 0 and world == 1 and not args.no_extras:
-        result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
+        try:
+            result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
+        except Exception as e:                                   # noqa: BLE001
+            log(f"extras leg failed: {e!r}")
+            result["extra"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)
+        try:
+            result["cpu_baseline"] = cpu_baseline(pq, chain, sql, args.seed, log)
+        except Exception as e:                                   # noqa: BLE001
+            log(f"cpu baseline failed: {e!r}")
+            result["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
     if xch is not None:
         xch.close()
     if qs is not None:
