@@ -92,6 +92,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t x) {
     uint32_t t = x;
@@ -966,8 +972,8 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
                 for (uint32_t i = 0; i < 16; i++) {
                     if (!((bits >> i) & 1u)) continue;
                     const int sidx = (int)(c + i);
-                    const uint64_t step_off = __shfl(my_off, sidx, 64);
-                    const uint32_t cwi = (uint32_t)__shfl((int)cw, sidx, 64);
+                    const uint64_t step_off = readlane_u64(my_off, sidx);           // sidx is wave-uniform: v_readlane, no LDS crossbar
+                    const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
                     expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
                                     cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
                 }
@@ -1022,8 +1028,8 @@ __global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
         for (uint32_t i = slot0; i < slot1; i++) {
             const int sidx = (int)(wave + kWaves * i);
             if (!((nonempty >> sidx) & 1ull)) continue;
-            const uint64_t step_off = __shfl(my_off, sidx, 64);
-            const uint32_t cwi = (uint32_t)__shfl((int)cw, sidx, 64);
+            const uint64_t step_off = readlane_u64(my_off, sidx);           // sidx is wave-uniform: v_readlane, no LDS crossbar
+            const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
             expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
                             cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
         }
