@@ -113,7 +113,10 @@ int  pqps_device_count(void);
  * --kernel-trace reports; a third event is recorded after the last kernel.
  * pqps_ctx_kernel_time waits for the recorded launches and returns: *eval_ms =
  * sum of the K1 durations, *total_ms = sum over the whole K1 -> K2 -> K3
- * pipeline, and their number; it then resets the recorder. */
+ * pipeline, and their number; it then resets the recorder.  While timing is on,
+ * pqps_qstream_scan / pqps_exchange_select run each query whole on the caller's
+ * stream with the context's own scratch (so that the events mean the above):
+ * issue them on ONE stream then. */
 int  pqps_ctx_set_timing(pqps_ctx *ctx, int enable);
 int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *launches);
 /* Fills name (<=63 chars), CU count and total HBM bytes of the ctx device. */
