@@ -337,6 +337,16 @@ def test_shim_rejects_malformed_calls(ctx):
     assert L.pqps_compact_rows(ctx.h, cols, nc, 10, None, C.byref(C.c_uint64()), None) == EINVAL
     assert L.pqps_compact_rows(ctx.h, cols, 0, 10, out.ids, C.byref(C.c_uint64()), None) == EINVAL
     assert L.pqps_exchange_select(None, cols, nc, 10, 0, C.byref(pred), 0, None) == EINVAL
+    assert L.pqps_qstream_scan(None, cols, nc, 10, 0, C.byref(pred), out.ids, out.cap, out.count, None) == EINVAL
+    assert L.pqps_qstream_create(ctx.h, 17, C.byref(C.c_void_p())) == EINVAL and L.pqps_qstream_create(None, 2, C.byref(C.c_void_p())) == EINVAL
+    assert L.pqps_project_column(ctx.h, cols, None, out.count, 10, 0, out.ids, None) == EINVAL
+    assert L.pqps_project_column(ctx.h, cols, out.ids, out.count, 10, 0, None, None) == EINVAL
+    assert L.pqps_gather_keys(ctx.h, cols, 1, out.ids, out.count, 10, 0, None, None) == EINVAL
+    u8col = pq.column_array([(cols[0].data, 1)])
+    assert L.pqps_gather_keys(ctx.h, u8col, 1, out.ids, out.count, 10, 0, out.ids, None) == EINVAL       # signed keys are 4 bytes wide
+    assert L.pqps_merge_index_slots(ctx.h, out.ids, None, 2, 100, out.ids, 10, out.count, None) == EINVAL
+    assert L.pqps_merge_index_slots(ctx.h, out.ids, out.ids, 2, 101, out.ids, 10, out.count, None) == EINVAL   # odd stride
+    assert L.pqps_ctx_reserve(None, 10) == EINVAL
     # a good call still works afterwards
     assert np.array_equal(gpu_scan(ctx, dev, QUERIES["Q_B"], out), q.HostSynth(10_000, seed=2).oracle_scan(QUERIES["Q_B"]))
     out.free()
