@@ -234,8 +234,23 @@ def main():
         pq.check(L.pqps_qstream_create(ctx.h, RING, C.byref(qs)), "pqps_qstream_create")
     xch, mergers = None, None
     if native:
-        xch = mg.ShardExchange(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING)
-    else:
+        # every rank must take the same path: if the shim-driven exchange cannot be set up on any of them
+        # (RCCL library not found, communicator refused), all fall back to the torch.distributed collectives
+        try:
+            xch = mg.ShardExchange(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING)
+            ok = 1
+        except Exception as e:                                   # noqa: BLE001
+            print(f"[bench] rank {rank}: shim-driven exchange unavailable ({e!r}); falling back to --exchange torch",
+                  file=sys.stderr, flush=True)
+            xch, ok = None, 0
+        agreed = torch.tensor([ok], dtype=torch.int64, device=cdev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            if xch is not None:
+                xch.close()
+                xch = None
+            native = False
+    if not native:
         mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq,
                                host_staged=(args.backend != "nccl"), always_collective=args.force_merge) for _ in range(RING)]
         comm = torch.cuda.Stream(device=device)

@@ -179,6 +179,8 @@ def default_rccl_library(torch=None):
     """The RCCL that goes with the HIP runtime this process runs on: under torch (which loads its
     own bundled libamdhip64 + librccl) the bundled one, otherwise the system one."""
     import os
+    if os.environ.get("PQPS_RCCL_LIBRARY"):
+        return os.environ["PQPS_RCCL_LIBRARY"]
     if torch is not None:
         p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         if os.path.exists(p):
