@@ -201,11 +201,14 @@ class ShardExchange:
         L = pq.lib()
         path = (rccl_library or default_rccl_library(torch)).encode()
         ident = C.create_string_buffer(128)
-        if rank == 0:
-            pq.check(L.pqps_exchange_unique_id(path, ident), "pqps_exchange_unique_id")
-        box = [ident.raw]
+        err = None
+        if rank == 0 and L.pqps_exchange_unique_id(path, ident) != 0:
+            err = "pqps_exchange_unique_id failed: " + L.pqps_last_error().decode()
+        box = [ident.raw, err]                       # rank 0's failure travels with the broadcast: every rank raises
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+        if box[1] is not None:
+            raise pq.PqpsError(box[1])
         ident = C.create_string_buffer(box[0], 128)
         h = C.c_void_p()
         pq.check(L.pqps_exchange_create(ctx.h, path, ident, world, rank, int(slot_capacity), ring, C.byref(h)),
