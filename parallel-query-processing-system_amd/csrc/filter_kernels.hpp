@@ -354,8 +354,25 @@ __device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_t
     }
 }
 
+// plain or streaming (`nt`) loads, see RawChunk::load
+template <bool NT> __device__ __forceinline__ uint4 ld_x4(const void *p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (NT) { const u32x4 q = __builtin_nontemporal_load((const u32x4 *)p); return make_uint4(q.x, q.y, q.z, q.w); }
+    else return *(const uint4 *)p;
+}
+template <bool NT> __device__ __forceinline__ uint2 ld_x2(const void *p) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (NT) { const u32x2 q = __builtin_nontemporal_load((const u32x2 *)p); return make_uint2(q.x, q.y); }
+    else return *(const uint2 *)p;
+}
+template <bool NT> __device__ __forceinline__ uint32_t ld_x1(const void *p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const uint32_t *)p);
+    else return *(const uint32_t *)p;
+}
+
 // ---- generic evaluators (any number of columns / leaves), RPL = 4 -----------------------
 // Fast path: all 1024 rows of the step exist and are contiguous.
+template <bool NT>
 __device__ __forceinline__ uint32_t eval_step_full(const EvalArgs &a, uint64_t step_row0, uint32_t lane) {
     constexpr int R = 16;
     uint32_t idx[R];
@@ -375,8 +392,8 @@ __device__ __forceinline__ uint32_t eval_step_full(const EvalArgs &a, uint64_t s
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const char *p = base + (lane_row0 + (uint64_t)(h + u) * 256) * 8;
-                    const uint4 q0 = *(const uint4 *)p;
-                    const uint4 q1 = *(const uint4 *)(p + 16);
+                    const uint4 q0 = ld_x4<NT>(p);
+                    const uint4 q1 = ld_x4<NT>(p + 16);
                     v[4 * u + 0] = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
                     v[4 * u + 1] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
                     v[4 * u + 2] = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
@@ -394,14 +411,14 @@ __device__ __forceinline__ uint32_t eval_step_full(const EvalArgs &a, uint64_t s
             for (int u = 0; u < 4; u++) {
                 const uint64_t r0 = lane_row0 + (uint64_t)u * 256;
                 if (wl == 2) {
-                    const uint4 q = *(const uint4 *)(base + r0 * 4);
+                    const uint4 q = ld_x4<NT>(base + r0 * 4);
                     v[4 * u] = q.x; v[4 * u + 1] = q.y; v[4 * u + 2] = q.z; v[4 * u + 3] = q.w;
                 } else if (wl == 1) {
-                    const uint2 q = *(const uint2 *)(base + r0 * 2);
+                    const uint2 q = ld_x2<NT>(base + r0 * 2);
                     v[4 * u] = q.x & 0xFFFFu; v[4 * u + 1] = q.x >> 16;
                     v[4 * u + 2] = q.y & 0xFFFFu; v[4 * u + 3] = q.y >> 16;
                 } else {
-                    const uint32_t q = *(const uint32_t *)(base + r0);
+                    const uint32_t q = ld_x1<NT>(base + r0);
                     v[4 * u] = q & 0xFFu; v[4 * u + 1] = (q >> 8) & 0xFFu;
                     v[4 * u + 2] = (q >> 16) & 0xFFu; v[4 * u + 3] = q >> 24;
                 }
@@ -463,7 +480,7 @@ __device__ __forceinline__ void clear_super_sums(const EvalArgs &a) {
         for (uint32_t i = threadIdx.x; i < a.n_super; i += kBlock) a.super_sum[(uint64_t)i * 512] = 0ull;   // kSuperStride
 }
 
-template <int MODE, bool GATHER>
+template <int MODE, bool GATHER, bool NT = false>
 __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) 
     for (uint64_t step = wave; step < steps_used; step += n_waves) {
         const uint64_t step_row0 = step * kStepRows;
         uint32_t mbits = 0;
-        if (!GATHER && step_row0 + kStepRows <= n_rows) mbits = eval_step_full(a, step_row0, lane);
+        if (!GATHER && step_row0 + kStepRows <= n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
         else if (step_row0 < n_rows) mbits = eval_step_guarded<GATHER>(a, step_row0, n_rows, begin, lane);
         emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
     }

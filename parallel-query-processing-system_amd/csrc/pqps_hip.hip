@@ -475,7 +475,7 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
             return f;
         }
     }
-    return eval_generic_kernel<MODE, false>;
+    return a.streaming ? eval_generic_kernel<MODE, false, true> : eval_generic_kernel<MODE, false, false>;
 }
 
 // Workgroups of K1.  Measured (fraction of 8 TB/s, S1 / Q_A / Q_C at 0.1 - 1 G rows): waves that
@@ -790,7 +790,7 @@ int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
     a.out_flags = out_flags;
-    return run_filter(ctx, eval_generic_kernel<MODE_FLAGS, false>, a, n_rows, MODE_FLAGS, false,
+    return run_filter(ctx, a.streaming ? eval_generic_kernel<MODE_FLAGS, false, true> : eval_generic_kernel<MODE_FLAGS, false, false>, a, n_rows, MODE_FLAGS, false,
                       0, nullptr, 0, out_count, s);
 }
 
