@@ -1,28 +1,38 @@
 // filter_kernels.hpp -- device code of the SELECT/WHERE filter (included once by pqps_hip.hip).
 //
 // Replaces linearSearchRecords + evaluateWhereClause + checkCondition + CMP_* of the
-// reference (engine/serial/executeEngine-serial.c:854-878, :292-316, :251-289, :18-123)
-// with three stream-ordered kernels, none of which ever waits on another workgroup:
+// reference (engine/serial/executeEngine-serial.c:854-878, :292-316, :251-289, :18-123).
 //
-//  K1 eval    one wave = one STEP of 1024 consecutive rows (16 rows per lane); grid-stride
-//             over steps, no LDS, no barriers.  Lane l owns RPL = 16/Wmax (4 for 8-byte) consecutive rows
-//             of each 64*RPL-row chunk, so the widest predicate column is read with ONE fully
-//             coalesced global_load_dwordx4 per chunk and narrower ones with dwordx2 / dword /
-//             ushort loads that are just as contiguous across the wave.  Every predicate
-//             column is read exactly once.  A leaf is the unsigned window test
-//             ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth table (<= 6
-//             leaves) or a jump table.  Output per step: 16 match bits per lane (one coalesced
-//             128-byte store, skipped when the step has no match) + the step's match count.
-//  K2 sums    per group of 64 steps a wave sums the counts; group sums are also added (one
-//             atomic per non-empty group) into supergroup sums of 64 groups.
-//  K3 expand  workgroup per group: its first output slot = supergroup sums before it + earlier
-//             group sums of its supergroup (a few hundred values, no serial scan); wave-prefix of
-//             the 64 step counts; for every non-empty step the match bits become ascending row
-//             IDs (ballot + mbcnt lane prefix).
+// ID output (the row-ID list of linearSearchRecords) is ONE launch whose workgroups play two roles:
 //
-// K1 dominates (it is the only kernel that touches the table) and is bound by HBM reads.
-// Width-specialised instantiations (1-3 predicate columns, widths non-increasing) keep all
-// loads statically scheduled; everything else takes the generic kernel.
+//  scan      a workgroup = one TILE of 4 (8 for a lone 1-byte column) consecutive steps, a wave = one STEP
+//            of 1024 consecutive rows (16 rows per lane), no loop: the dispatcher deals the tiles out in
+//            address order, so the chip reads one contiguous, advancing window of every predicate column.
+//            Lane l owns RPL = 16/Wmax (4 for 8-byte) consecutive rows of each 64*RPL-row chunk, so the
+//            widest predicate column is ONE fully coalesced global_load_dwordx4 per chunk and narrower
+//            ones dwordx2 / dword / ushort loads that are just as contiguous across the wave.  A leaf is
+//            the unsigned window test ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth
+//            table (<= 6 leaves) or a jump table.  Output per step: 16 match bits per lane (128 bytes,
+//            skipped when the step has no match) and the step's match count; per tile ONE agent-scope
+//            atomic add of (steps, matches) to the word of its GROUP (64 steps = 64 K rows).
+//  expand    a workgroup per group, placed in the grid `lag` groups behind the group's scan tiles: waits
+//            (normally not at all) until its group and everything in front of it has arrived, derives
+//            its first output slot from the supergroup words (64 groups each) and the earlier group
+//            words of its own supergroup, and turns the match bits into ascending row IDs.  Its integer
+//            work runs in the shadow of the bandwidth-bound scan tiles around it; only the last `lag`
+//            groups are expanded after the last table byte has been read.
+//
+// Hand-off between the roles follows the write-through form of the CDNA4 guide: payload (match bits,
+// step counts) stored sc1, every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's
+// barrier, one lane signals with an agent-scope atomic; the consumer polls with sc1 loads and reads the
+// payload with sc1 loads only.  No result depends on dispatch order: an expander's wait is bounded, a
+// group whose wait ran out is left to the expander that is last to leave its wait (one workgroup, so it
+// cannot starve the tiles it waits for), and the words of a query are zeroed by the next query on the
+// other half of a ping-pong pair.
+//
+// COUNT(*) / DELETE flags keep the grid-stride form of the scan (no ID list, no hand-off).
+// Width-specialised instantiations (1-3 predicate columns, widths non-increasing) keep all loads
+// statically scheduled; everything else takes the generic kernel.
 #pragma once
 
 namespace {
@@ -42,14 +52,29 @@ struct EvalArgs {
     uint64_t truth;
     uint64_t n_rows;                 // scan: rows; gather: caller's upper bound (range is on the device)
     uint16_t *masks;                 // [steps][64] match bits of every lane
-    uint32_t *counts;                // [steps]     matches | log2(RPL) << 28
+    uint32_t *counts;                // [steps]     matches | log2(RPL) << 28; all zero between queries
     uint8_t *out_flags;              // MODE_FLAGS
     uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
-    unsigned long long *super_sum;   // MODE_IDS: [n_super] zeroed here for the K2 that follows
-    uint32_t n_super;
-    uint32_t pad1;
     const uint32_t *cand;            // gather: candidate row numbers
     const uint64_t *range;           // gather: [begin, end) into cand, device resident
+    // ---- ID output: hand-off words of this query (one half of the ping-pong pair) and the result ----
+    uint64_t *gword;                 // [groups]  steps arrived << 48 | matches
+    uint64_t *sword;                 // [supers]  groups forwarded << 48 | matches
+    uint32_t *ctl;                   // [kCtlWords] expanders past their wait, deferred groups
+    uint32_t *deferred;              // [groups]  1 = left to the recovery pass, | 2 = already forwarded
+    uint64_t *zgword, *zsword;       // the other half: zeroed here for the query after this one
+    uint32_t *zctl, *zdeferred;
+    uint64_t zero_groups;            // ... as far as its last query can have written
+    uint64_t *base_slot;             // gather: first output slot (= *out_count when the launch began)
+    uint32_t *status;                // sticky error word of the context (a wait that never ended)
+    uint32_t *out_ids;
+    uint64_t out_cap;
+    uint64_t *out_count;
+    uint64_t block_base;             // added to blockIdx.x (the trailing expanders can be a launch of their own)
+    uint32_t id_base;
+    uint32_t lag;                    // groups between a group's scan tiles and its expander in the grid
+    uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
+    uint32_t accumulate;             // gather: append behind *out_count
     uint32_t n_cols;
     uint32_t n_leaves;
     uint32_t negmask;
@@ -58,7 +83,6 @@ struct EvalArgs {
     uint32_t valu_chain;             // host side only: the one-leaf vector-unit kernel variant was chosen
     uint32_t chain;                  // 0: general tree; 1: AND of leaves; 2: NOT(AND) = OR form (spec kernels)
     uint32_t chain_want;             // bit k: raw window hit that leaf slot k must have inside the AND
-    uint32_t pad0;
     uint8_t width_log2[PQPS_MAX_COLUMNS];
     uint8_t leaf_begin[PQPS_MAX_COLUMNS + 1];   // leaves of column c: [leaf_begin[c], leaf_begin[c+1])
     uint8_t on_true[PQPS_MAX_LEAVES];
@@ -233,34 +257,37 @@ __device__ __forceinline__ uint32_t combine_masks(const EvalArgs &a, const LeafM
 
 // ---- per-step output ---------------------------------------------------------------
 // Bit p of a lane's 16 match bits <-> row  step_row0 + (p / RPL) * 64 * RPL + lane * RPL + p % RPL.
-// 128 B of match bits of one step: the 16-bit words of 8 neighbouring lanes are gathered into
-// one lane (DPP), 8 lanes store 16 B each.
+// 128 B of match bits of one step: the 16-bit words of 4 neighbouring lanes are gathered into one lane
+// (DPP), 16 lanes store 8 B each -- write-through (sc1): the expander that reads them runs on another CU,
+// possibly on another XCD whose L2 never sees this one's dirty lines.
+#define PQPS_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ uint64_t ld_sc1(const uint64_t *p) { return __hip_atomic_load(p, PQPS_AGENT); }
+__device__ __forceinline__ uint32_t ld_sc1(const uint32_t *p) { return __hip_atomic_load(p, PQPS_AGENT); }
+__device__ __forceinline__ uint16_t ld_sc1(const uint16_t *p) { return __hip_atomic_load(p, PQPS_AGENT); }
+__device__ __forceinline__ void st_sc1(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, PQPS_AGENT); }
+__device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, PQPS_AGENT); }
+// every store of the calling wave has reached the memory side (the asm is invisible to the passes that
+// drop a builtin wait they can prove redundant)
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void store_mask(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t lane) {
-    const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // lane pairs (even lanes valid)
-    const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lane+2's pair
-    const uint32_t q0 = w2, q1 = w2b;                                              // lanes 0 mod 4: words 0..3
-    const uint32_t q2 = dpp_or_zero<0x104>(q0), q3 = dpp_or_zero<0x104>(q1);       // row_shl:4 -> lane+4's words
-    if ((lane & 7u) == 0) {
-        uint4 v; v.x = q0; v.y = q1; v.z = q2; v.w = q3;
-        *(uint4 *)(a.masks + step * 64 + lane) = v;
-    }
+    const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // even lanes: own word | next lane's
+    const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lanes 0 mod 4: the pair of lane + 2
+    if ((lane & 3u) == 0)
+        st_sc1((uint64_t *)(a.masks + step * 64 + lane), (uint64_t)w2 | ((uint64_t)w2b << 32));
 }
 
+// COUNT / FLAGS modes (grid-stride scan, no hand-off)
 template <int MODE>
 __device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t rpl_log2,
                                           uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
-    const uint32_t cnt = wave_sum_u32(__popc(mbits));
-    if (MODE == MODE_IDS) {
-        if (cnt) store_mask(a, step, mbits, lane);               // 128 B per step, only if needed
-        if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
-    } else {
-        wave_total += cnt;
-        if (MODE == MODE_FLAGS) {
-            const uint32_t rpl = 1u << rpl_log2;
-            for (uint32_t p = 0; p < 16; p++) {
-                const uint64_t row = step * kStepRows + (uint64_t)(p >> rpl_log2) * 64 * rpl + lane * rpl + (p & (rpl - 1));
-                if (row < n_rows) a.out_flags[row] = (uint8_t)((mbits >> p) & 1u);
-            }
+    static_assert(MODE != MODE_IDS, "ID output is the tile / expander form");
+    wave_total += wave_sum_u32(__popc(mbits));
+    if (MODE == MODE_FLAGS) {
+        const uint32_t rpl = 1u << rpl_log2;
+        for (uint32_t p = 0; p < 16; p++) {
+            const uint64_t row = step * kStepRows + (uint64_t)(p >> rpl_log2) * 64 * rpl + lane * rpl + (p & (rpl - 1));
+            if (row < n_rows) a.out_flags[row] = (uint8_t)((mbits >> p) & 1u);
         }
     }
 }
@@ -324,18 +351,6 @@ __device__ __forceinline__ void fold_half(const EvalArgs &a, RowPlanes &acc, uin
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ void emit_chain_step(const EvalArgs &a, uint64_t step, uint32_t cnt, uint32_t mbits,
-                                                uint32_t rpl_log2, uint32_t lane, uint64_t &wave_total) {
-    static_assert(MODE != MODE_FLAGS, "flag output goes through the generic kernel");
-    if (MODE == MODE_IDS) {
-        if (cnt) store_mask(a, step, mbits, lane);
-        if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
-    } else {
-        wave_total += cnt;
-    }
-}
-
 // COUNT / FLAGS modes: every workgroup adds its total into one of kPartialSlots counters (the grid
 // can be far larger than that; spread over 4096 addresses the atomics do not queue up), which
 // reduce_totals_kernel sums and leaves zeroed for the next query.
@@ -343,7 +358,7 @@ constexpr uint32_t kPartialSlots = 4096;
 
 template <int MODE>
 __device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_total) {
-    if (MODE == MODE_IDS) return;
+    static_assert(MODE != MODE_IDS, "ID output is the tile / expander form");
     __shared__ uint64_t s_tot[kWaves];
     if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = wave_total;
     __syncthreads();
@@ -471,41 +486,415 @@ __device__ __forceinline__ uint32_t eval_step_guarded(const EvalArgs &a, uint64_
     return mbits;
 }
 
-// Generic K1: any predicate; scan (full steps vectorised) or gather (always guarded).
-// K2 accumulates supergroup sums with atomics; the first workgroup of K1 clears them -- at its END,
-// so that no workgroup starts with a kernel-argument round trip for something only K2 needs.
-template <int MODE>
-__device__ __forceinline__ void clear_super_sums(const EvalArgs &a) {
-    if (MODE == MODE_IDS && blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < a.n_super; i += kBlock) a.super_sum[(uint64_t)i * 512] = 0ull;   // kSuperStride
+// ---- ID output: tiles, groups, and the hand-off between scan and expand workgroups ------------------
+// group = 64 steps (64 K rows); supergroup = 64 groups (4 M rows).  A hand-off word = arrivals << 48 | matches.
+constexpr int kSuperGroups = 64;
+constexpr int kArrShift = 48;
+constexpr uint64_t kSumMask = (1ull << kArrShift) - 1ull;
+constexpr int kCtlWords = 16;               // ctl[0]: expanders past their wait; ctl[1]: groups left to the recovery pass
+constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches writes its IDs lane by lane
+constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
+
+struct FusedShared {
+    uint16_t mask[kWaves][kGroupSteps / kWaves][64];   // expander: match words of a wave's 16 steps
+    uint32_t counts[kGroupSteps];                       // expander: step counts of the group
+    uint32_t tile_cnt[16];                              // scan: step counts of the tile
+    uint64_t group_off;                                 // expander: first output slot of the group
+    uint32_t state;                                     // expander: 1 = expand now, 0 = deferred
+    uint32_t recover;                                   // expander: this workgroup runs the recovery pass
+};
+
+// What this launch covers: a scan of n_rows rows, or (gather) the device-side candidate range clamped
+// to the caller's bound.
+struct Extent { uint64_t begin, n_rows, steps, groups; };
+
+template <bool GATHER>
+__device__ __forceinline__ Extent scan_extent(const EvalArgs &a) {
+    Extent e;
+    e.begin = 0;
+    e.n_rows = a.n_rows;
+    if (GATHER) {
+        e.begin = a.range[0];
+        const uint64_t end = a.range[1];
+        uint64_t n = end > e.begin ? end - e.begin : 0;
+        if (n > a.n_rows) n = a.n_rows;                         // never past the caller's bound
+        e.n_rows = n;
+    }
+    e.steps = (e.n_rows + kStepRows - 1) / kStepRows;
+    e.groups = (e.steps + kGroupSteps - 1) / kGroupSteps;
+    return e;
 }
 
+// Grid layout (TPG tiles per group): the tiles of group q are followed by the expander of group q - lag;
+// the expanders of the last `lag` groups come after the last tile.  Placement is for speed only -- an
+// expander checks what it needs and waits (bounded) if it is early.
+enum { ROLE_NONE = 0, ROLE_SCAN = 1, ROLE_EXPAND = 2 };
+struct Role { uint32_t kind; uint32_t index; };
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    return (uint64_t)uniform_u32((uint32_t)v) | ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32);
+}
+
+// All in 32 bits (the host keeps a launch under 2^31 workgroups) and pinned to SGPRs: the role and everything
+// derived from it is wave-uniform, and a 64-bit division would be done -- and then kept -- in vector registers.
+template <int TPG>
+__device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
+    constexpr uint32_t period = TPG + 1;
+    const uint32_t b = blockIdx.x + (uint32_t)a.block_base;
+    const uint32_t main_blocks = groups * period;
+    const uint32_t lag = a.lag < groups ? a.lag : groups;
+    Role r;
+    r.kind = ROLE_NONE;
+    r.index = 0;
+    if (b < main_blocks) {
+        const uint32_t q = b / period, rr = b % period;
+        if (rr < TPG) { r.kind = ROLE_SCAN; r.index = q * TPG + rr; }
+        else if (q >= lag) { r.kind = ROLE_EXPAND; r.index = q - lag; }
+    } else if (b - main_blocks < lag) {
+        r.kind = ROLE_EXPAND;
+        r.index = groups - lag + (b - main_blocks);
+    }
+    r.kind = uniform_u32(r.kind);
+    r.index = uniform_u32(r.index);
+    return r;
+}
+
+// The hand-off words of a query are zeroed by the NEXT query of the context, which runs on the other half
+// of the ping-pong pair (plain stores: the kernel boundary publishes them).
+__device__ __forceinline__ void zero_other_half(const EvalArgs &a) {
+    if (a.block_base != 0) return;
+    const uint64_t n = a.zero_groups, ns = (n + kSuperGroups - 1) / kSuperGroups;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        a.zgword[i] = 0ull;
+        a.zdeferred[i] = 0u;
+        if (i < ns) a.zsword[i] = 0ull;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < kCtlWords) a.zctl[threadIdx.x] = 0u;
+}
+
+// End of a scan tile of TS steps.  Every wave has left the counts of its steps in sh.tile_cnt, drained its
+// match-word stores and passed the workgroup's barrier; wave 0 publishes: the non-zero counts (the array is
+// all zero between queries), then ONE atomic add of (steps, matches) to the tile's group word.
+template <int TS>
+__device__ __forceinline__ void publish_tile(const EvalArgs &a, const FusedShared &sh, const Extent &ex, uint64_t tile, uint32_t lane) {
+    const uint64_t first = tile * TS;
+    const uint32_t steps_in_tile = ex.steps - first < (uint64_t)TS ? (uint32_t)(ex.steps - first) : (uint32_t)TS;
+    const uint32_t c = lane < steps_in_tile ? sh.tile_cnt[lane] : 0u;
+    const uint32_t total = wave_sum_u32(c & 0x0FFFFFFFu);
+    bool stored = false;
+    if (tile == 0 && a.accumulate) {                            // gather: results are appended behind *out_count
+        if (lane == 0) st_sc1(a.base_slot, *a.out_count);
+        stored = true;
+    }
+    if (total) {
+        if (c & 0x0FFFFFFFu) st_sc1(a.counts + first + lane, c);
+        stored = true;
+    }
+    if (stored) drain_stores();
+    if (lane == 0)
+        __hip_atomic_fetch_add(a.gword + first / kGroupSteps, ((uint64_t)steps_in_tile << kArrShift) | (uint64_t)total, PQPS_AGENT);
+}
+
+// One wave's share of a scan tile: count word into LDS, match words (if any) to memory and drained.
+__device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
+                                              uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
+    if (cnt) store_mask(a, step, mbits, lane);
+    if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << 28);
+}
+
+// ---- expand: match words -> ascending row IDs ------------------------------------------------------------
+// One step: the scan left 16 match bits per lane in its load layout (bit p of lane l <-> row
+// (p / RPL) * 64 * RPL + l * RPL + p % RPL).  First bring them into ROW order -- lane d gets the bits of rows
+// 16d .. 16d+15, which sit in 16/RPL source lanes.  Then
+//   few matches:  one wave scan of the per-lane popcounts gives every lane its first output slot; a lane writes
+//                 the IDs of its set bits one after the other (neighbouring lanes write neighbouring slots);
+//   many matches: 64 rows at a time -- their match bits are the words of 4 lanes, read into an SGPR pair with
+//                 v_readlane; rank inside the 64 = mbcnt, so the 64 lanes store to consecutive slots.
+// Neither form touches LDS.
+template <int RL>                                               // log2(RPL): 2, 3 or 4
+__device__ __forceinline__ uint32_t row_order_word(uint32_t m16, uint32_t lane) {
+    constexpr uint32_t RPL = 1u << RL, S = 16u / RPL;              // S source lanes per destination lane
+    if constexpr (S == 1) {
+        return m16;
+    } else {
+        constexpr uint32_t LPC = 64u / S;                           // destination lanes per chunk
+        const uint32_t u = lane / LPC, first = S * (lane % LPC);
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < S; q++) {
+            const uint32_t src = (uint32_t)__shfl((int)m16, (int)(first + q), 64);
+            word |= ((src >> (RPL * u)) & ((1u << RPL) - 1u)) << (RPL * q);
+        }
+        return word;
+    }
+}
+
+__device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t m16, uint32_t rpl_log2,
+                                            uint32_t count, uint64_t out_off, uint32_t lane) {
+    uint32_t word;
+    switch (rpl_log2) {                                             // uniform
+    case 2: word = row_order_word<2>(m16, lane); break;
+    case 3: word = row_order_word<3>(m16, lane); break;
+    default: word = m16; break;
+    }
+    const bool gather = a.cand != nullptr;                          // uniform
+    const uint32_t step_row0 = (uint32_t)(step * kStepRows);
+    if (count <= kDirectIds) {
+        const uint32_t cnt = __popc(word);
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        uint64_t pos = out_off + (incl - cnt);
+        const uint32_t r0 = step_row0 + lane * 16u;
+        while (word) {                                              // set bits only, ascending rows
+            const uint32_t j = (uint32_t)__builtin_ctz(word);
+            word &= word - 1;
+            // gather: the candidate number of the row (a set bit implies the row lies inside the probed range)
+            const uint32_t id = gather ? a.cand[begin + r0 + j] : r0 + j;
+            if (pos < a.out_cap) a.out_ids[pos] = id + a.id_base;
+            pos++;
+        }
+    } else {
+        uint64_t base = out_off;
+#pragma unroll 1
+        for (uint32_t s = 0; s < 16; s++) {
+            // the match bits of rows 64s .. 64s+63 are the words of lanes 4s .. 4s+3: wave-uniform lane numbers, so
+            // v_readlane (SGPR result), no LDS crossbar
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s));
+            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 1));
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 2));
+            const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 3));
+            const uint64_t b = (uint64_t)(w0 | (w1 << 16)) | ((uint64_t)(w2 | (w3 << 16)) << 32);
+            if (b) {                                                // uniform
+                if ((b >> lane) & 1ull) {
+                    const uint64_t o = base + mbcnt(b);
+                    const uint32_t row = step_row0 + 64u * s + lane;
+                    const uint32_t id = gather ? a.cand[begin + row] : row;
+                    if (o < a.out_cap) a.out_ids[o] = id + a.id_base;
+                }
+                base += (uint64_t)__popcll(b);
+            }
+        }
+    }
+}
+
+// Steps of group g that exist (the last group can be short).
+__device__ __forceinline__ uint32_t group_steps(const Extent &ex, uint64_t g) {
+    const uint64_t left = ex.steps - g * kGroupSteps;
+    return left < (uint64_t)kGroupSteps ? (uint32_t)left : (uint32_t)kGroupSteps;
+}
+
+// Polls (one wave, all lanes the same word) until every step of group g has arrived.
+__device__ __forceinline__ bool wait_group(const EvalArgs &a, uint64_t g, uint32_t need, uint32_t limit, uint64_t &sum) {
+    for (uint32_t spins = 0;; spins++) {
+        const uint64_t w = ld_sc1(a.gword + g);
+        if ((uint32_t)(w >> kArrShift) == need) { sum = w & kSumMask; return true; }
+        if (spins >= limit) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// Polls until everything in front of group g has arrived -- the supergroups before its own (every group
+// forwarded) and the groups before it in its own supergroup -- and sums their matches.
+__device__ __forceinline__ bool wait_prefix(const EvalArgs &a, uint64_t g, uint32_t limit, uint32_t lane, uint64_t &psum) {
+    const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
+    for (uint32_t spins = 0;; spins++) {
+        bool ok = true;
+        uint64_t acc = 0;
+        for (uint64_t j = lane; j < sg; j += 64) {
+            const uint64_t w = ld_sc1(a.sword + j);
+            ok = ok && (uint32_t)(w >> kArrShift) == (uint32_t)kSuperGroups;
+            acc += w & kSumMask;
+        }
+        if (lane < g_in) {
+            const uint64_t w = ld_sc1(a.gword + sg * kSuperGroups + lane);
+            ok = ok && (uint32_t)(w >> kArrShift) == (uint32_t)kGroupSteps;
+            acc += w & kSumMask;
+        }
+        if (__all(ok)) { psum = wave_sum_u64(acc); return true; }
+        if (spins >= limit) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// Wave 0, once group g and everything in front of it has arrived: the group's step counts go to LDS for the
+// four waves, and back to zero in memory for the next query.
+__device__ __forceinline__ void fetch_group_counts(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane) {
+    const uint64_t step = g * kGroupSteps + lane;
+    uint32_t c = 0;
+    if (step < ex.steps) {
+        c = ld_sc1(a.counts + step);
+        if (c) st_sc1(a.counts + step, 0u);
+    }
+    sh.counts[lane] = c;
+}
+
+// All four waves: wave w turns the match words of steps 16w .. 16w+15 of group g into row IDs.
+__device__ __forceinline__ void expand_group(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t wave) {
+    const uint32_t cw = sh.counts[lane];
+    const uint64_t group_off = sh.group_off;
+    const uint32_t my_cnt = cw & 0x0FFFFFFFu;
+    const uint32_t incl = wave_incl_scan_u32(my_cnt);
+    const uint64_t my_off = group_off + (incl - my_cnt);
+    if (g + 1 == ex.groups && wave == 0 && lane == 63) *a.out_count = group_off + incl;
+    const uint64_t nonempty = __ballot(my_cnt != 0);
+    const uint32_t c0 = wave * (kGroupSteps / kWaves);
+    const uint32_t bits = uniform_u32((uint32_t)(nonempty >> c0) & 0xFFFFu);
+    if (!bits) return;                                              // uniform for the wave
+    // All match words of the wave's non-empty steps are requested at once (one memory latency) and parked in LDS:
+    // slot k takes the k-th non-empty step; slots past the last one re-read the first (no branch between the
+    // loads, and a line this wave has just asked for).
+    const uint16_t *gmask = a.masks + (g * kGroupSteps + c0) * 64 + lane;
+    const uint32_t first = (uint32_t)__builtin_ctz(bits);
+    uint32_t rest = bits;
+    uint32_t mreg[kGroupSteps / kWaves];
+#pragma unroll
+    for (uint32_t k = 0; k < kGroupSteps / kWaves; k++) {
+        const uint32_t i = rest ? (uint32_t)__builtin_ctz(rest) : first;                 // wave-uniform
+        rest &= rest - 1;
+        mreg[k] = ld_sc1(gmask + (size_t)i * 64);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kGroupSteps / kWaves; k++) sh.mask[wave][k][lane] = (uint16_t)mreg[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave wrote and reads
+    rest = bits;
+    for (uint32_t k = 0; rest; k++) {
+        const int sidx = (int)(c0 + (uint32_t)__builtin_ctz(rest));
+        rest &= rest - 1;
+        const uint64_t step_off = readlane_u64(my_off, sidx);       // sidx is wave-uniform: v_readlane, no LDS crossbar
+        const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
+        expand_step(a, ex.begin, g * kGroupSteps + (uint64_t)sidx, sh.mask[wave][k][lane], cwi >> 28, cwi & 0x0FFFFFFFu,
+                    step_off, lane);
+    }
+}
+
+// The expander workgroup of group g.
+//
+// Recovery: the ONE expander workgroup that is last to leave its wait looks after the groups others gave up
+// on (which in-order dispatch never produces).  By then every other expander is past its wait, so this
+// workgroup is the only one on the chip that waits for anything, and what it waits for are scan tiles, which
+// wait for nothing.  It first forwards what was never forwarded, then runs the same body over the deferred
+// groups in ascending order.
+__device__ __forceinline__ void expander(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g) {
+    const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
+    uint32_t ticket = 0;
+    bool recovery = false;                                          // uniform for the workgroup
+    uint64_t g0 = 0, todo = 0;                                      // recovery: deferred groups of [g0, g0 + 64) still to do
+    for (;;) {
+        if (wave == 0) {
+            uint64_t sum = 0, psum = 0;
+            uint32_t flags = 1u;
+            bool ok = true;
+            if (!recovery) {
+                ok = wait_group(a, g, group_steps(ex, g), a.spin_limit, sum);
+                if (ok) {
+                    // forward the group's matches to its supergroup word as soon as they are known: later supergroups wait for it
+                    if (lane == 0) __hip_atomic_fetch_add(a.sword + g / kSuperGroups, (1ull << kArrShift) | sum, PQPS_AGENT);
+                    flags |= 2u;
+                }
+            }
+            if (ok) ok = wait_prefix(a, g, recovery ? kRecoverSpins : a.spin_limit, lane, psum);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: payload loads stay behind the polls
+            if (ok) {
+                const uint64_t base = a.accumulate ? ld_sc1(a.base_slot) : 0ull;
+                fetch_group_counts(a, sh, ex, g, lane);
+                if (lane == 0) sh.group_off = base + psum;
+            } else if (recovery) {
+                if (lane == 0) st_sc1(a.status, 1u);                // something never arrived: reported, never silent
+            } else {
+                if (lane == 0) {
+                    st_sc1(a.deferred + g, flags);
+                    __hip_atomic_fetch_add(a.ctl + 1, 1u, PQPS_AGENT);
+                }
+                drain_stores();                                     // ... before this workgroup counts as past its wait
+            }
+            if (lane == 0) {
+                if (!recovery) ticket = __hip_atomic_fetch_add(a.ctl + 0, 1u, PQPS_AGENT);   // used after the expansion: latency hidden
+                sh.state = ok ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (sh.state) expand_group(a, sh, ex, g, lane, wave);
+        if (!recovery) {
+            if (wave == 0 && lane == 0)
+                sh.recover = ((uint64_t)ticket + 1 == ex.groups && ld_sc1(a.ctl + 1) != 0u) ? 1u : 0u;
+            __syncthreads();
+            if (!sh.recover) return;
+            recovery = true;
+            if (wave == 0) {                                        // pass 1: forward what was never forwarded
+                bool alive = true;
+                for (uint64_t f0 = 0; alive && f0 < ex.groups; f0 += 64) {
+                    const uint32_t f = f0 + lane < ex.groups ? ld_sc1(a.deferred + f0 + lane) : 0u;
+                    uint64_t fw = __ballot((f & 3u) == 1u);         // deferred and not forwarded
+                    while (alive && fw) {
+                        const uint64_t gg = f0 + (uint64_t)__builtin_ctzll(fw);
+                        fw &= fw - 1;
+                        uint64_t sum = 0;
+                        alive = wait_group(a, gg, group_steps(ex, gg), kRecoverSpins, sum);
+                        if (alive && lane == 0) __hip_atomic_fetch_add(a.sword + gg / kSuperGroups, (1ull << kArrShift) | sum, PQPS_AGENT);
+                    }
+                }
+                if (!alive && lane == 0) st_sc1(a.status, 1u);
+            }
+            g0 = 0;
+            const uint32_t f = lane < ex.groups ? ld_sc1(a.deferred + lane) : 0u;
+            todo = __ballot((f & 1u) != 0u);
+        }
+        // next deferred group (every wave reads the same flags: nobody writes them any more)
+        while (todo == 0) {
+            g0 += 64;
+            if (g0 >= ex.groups) return;
+            const uint32_t f = g0 + lane < ex.groups ? ld_sc1(a.deferred + g0 + lane) : 0u;
+            todo = __ballot((f & 1u) != 0u);
+        }
+        g = g0 + (uint64_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        __syncthreads();                                            // everyone is done with the previous group's LDS
+    }
+}
+
+// Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
 template <int MODE, bool GATHER, bool NT = false>
-__global__ __launch_bounds__(kBlock) void eval_generic_kernel(const EvalArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
-    uint64_t begin = 0, n_rows = a.n_rows;
-    if (GATHER) {
-        begin = a.range[0];
-        const uint64_t end = a.range[1];
-        n_rows = end > begin ? end - begin : 0;
-        if (n_rows > a.n_rows) n_rows = a.n_rows;               // never past the caller's bound
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic_kernel(const EvalArgs a) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if constexpr (MODE == MODE_IDS) {
+        constexpr int TS = kWaves;                              // steps per tile
+        __shared__ FusedShared sh;
+        zero_other_half(a);
+        const Extent ex = scan_extent<GATHER>(a);
+        const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
+        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
+        const uint64_t step = (uint64_t)role.index * TS + wv;
+        uint32_t cnt = 0;
+        if (step < ex.steps) {
+            const uint64_t step_row0 = step * kStepRows;
+            uint32_t mbits;
+            if (!GATHER && step_row0 + kStepRows <= ex.n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
+            else mbits = eval_step_guarded<GATHER>(a, step_row0, ex.n_rows, ex.begin, lane);
+            cnt = wave_sum_u32(__popc(mbits));
+            tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
+        } else if (lane == 0) {
+            sh.tile_cnt[wv] = 0;
+        }
+        if (cnt) drain_stores();
+        __syncthreads();
+        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+    } else {
+        static_assert(!GATHER, "gather mode produces ID lists");
+        const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
+        const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+        const uint64_t n_rows = a.n_rows;
+        const uint64_t steps_used = (n_rows + kStepRows - 1) / kStepRows;
+        uint64_t wave_total = 0;
+        for (uint64_t step = wave; step < steps_used; step += n_waves) {
+            const uint64_t step_row0 = step * kStepRows;
+            uint32_t mbits = 0;
+            if (step_row0 + kStepRows <= n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
+            else mbits = eval_step_guarded<false>(a, step_row0, n_rows, 0, lane);
+            emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
+        }
+        finish_totals<MODE>(a, wave_total);
     }
-    // gather: the host sized the launch and counts[] for a.n_rows candidates, but only the steps of the
-    // device-side range are evaluated (K2 / K3 derive the same bound): a narrow probe costs three
-    // near-empty launches, not a pass over the whole table's step array
-    const uint64_t steps_used = (n_rows + kStepRows - 1) / kStepRows;
-    uint64_t wave_total = 0;
-    for (uint64_t step = wave; step < steps_used; step += n_waves) {
-        const uint64_t step_row0 = step * kStepRows;
-        uint32_t mbits = 0;
-        if (!GATHER && step_row0 + kStepRows <= n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
-        else if (step_row0 < n_rows) mbits = eval_step_guarded<GATHER>(a, step_row0, n_rows, begin, lane);
-        emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
-    }
-    clear_super_sums<MODE>(a);
-    finish_totals<MODE>(a, wave_total);
 }
 
 // ---- width-specialised K1 ---------------------------------------------------------------
@@ -669,9 +1058,10 @@ struct RawStep {
     // VC: the vector-unit variant for ONE comparison on ONE column -- a kernel of its own, so that its registers
     // do not weigh on the ballot path's occupancy.  (The same idea for chains of two or three leaves was
     // measured too: no gain -- with 3+ bytes per row the scalar unit is not what limits the scan.)
+    // One step of a chain predicate: ID output -> the step's match count and the lanes' match bits;
+    // COUNT -> cnt (ballot path) or lane_total (vector-unit path, summed once per wave at the end).
     template <int MODE, bool VC>
-    __device__ __forceinline__ void eval_chain_emit(const EvalArgs &a, uint64_t step, uint32_t rpl_log2, uint32_t lane,
-                                                    uint64_t &wave_total, uint32_t &lane_total) const {
+    __device__ __forceinline__ void eval_chain_step(const EvalArgs &a, uint32_t &cnt, uint32_t &mbits, uint32_t &lane_total) const {
         if constexpr (VC) {
             static_assert(W1 == 0 && W2 == 0, "one column");
             uint32_t m = 0;
@@ -685,15 +1075,12 @@ struct RawStep {
                 one_leaf<MODE, uint32_t>(a, v, m, lane_total);
             }
             if (MODE == MODE_IDS) {
-                const uint32_t cnt = wave_sum_u32(__popc(m));
-                if (cnt) store_mask(a, step, m, lane);
-                if (lane == 0) a.counts[step] = cnt | (rpl_log2 << 28);
+                cnt = wave_sum_u32(__popc(m));
+                mbits = m;
             }
         } else {
-            uint32_t cnt = 0, mbits = 0;
             eval_chain_half<MODE, 0>(a, cnt, mbits);
             eval_chain_half<MODE, 1>(a, cnt, mbits);
-            emit_chain_step<MODE>(a, step, cnt, mbits, rpl_log2, lane, wave_total);
         }
     }
     __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {     // <= 6 leaves: row-mask path
@@ -713,128 +1100,143 @@ struct RawStep {
 // wave has a byte of the table in flight -- which a one-shot workgroup pays on every launch.
 #define PQPS_HOIST_KERNARGS(a)                                                                        \
     asm volatile("" :: "s"((a).n_rows), "s"((a).col[0]), "s"((a).col[1]), "s"((a).col[2]), "s"(gridDim.x),  \
-                 "s"((a).masks), "s"((a).counts), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask),     \
+                 "s"((a).masks), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask),     \
                  "s"((uint32_t)(a).leaf_begin[0]), "s"((uint32_t)(a).leaf_begin[1]), "s"((uint32_t)(a).leaf_begin[2]), \
                  "s"((uint32_t)(a).leaf_begin[3]))
 
-// General tree of <= 6 leaves (row-mask path), one step per iteration.
+// General tree of <= 6 leaves (row-mask path).
 template <int MODE, int W0, int W1, int W2, bool NT>
-__global__ __launch_bounds__(kBlock) void eval_spec_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_spec_kernel(const EvalArgs a) {
     // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;                                 // chunks per step
     PQPS_HOIST_KERNARGS(a);
     const uint64_t n_rows = a.n_rows;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
-    uint64_t wave_total = 0;
-    for (uint64_t step = wave; step < full_steps; step += n_waves) {
-        RawStep<W0, W1, W2, RPL, U> A;
-        A.template load<NT>(a, step * kStepRows + lane_off);
-        emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
+    if constexpr (MODE == MODE_IDS) {
+        constexpr int TS = kWaves;
+        __shared__ FusedShared sh;
+        zero_other_half(a);
+        const Extent ex = scan_extent<false>(a);
+        const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
+        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
+        const uint64_t step = (uint64_t)role.index * TS + wv;
+        uint32_t cnt = 0;
+        if (step < full_steps) {
+            RawStep<W0, W1, W2, RPL, U> A;
+            A.template load<NT>(a, step * kStepRows + lane_off);
+            const uint32_t mbits = A.eval(a);
+            cnt = wave_sum_u32(__popc(mbits));
+            tile_step_out(a, sh, wv, step, cnt, mbits, log2i(RPL), lane);
+        } else if (step < ex.steps) {                           // the partial last step: guarded evaluator, RPL = 4 layout
+            const uint32_t mbits = eval_step_guarded<false>(a, step * kStepRows, n_rows, 0, lane);
+            cnt = wave_sum_u32(__popc(mbits));
+            tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
+        } else if (lane == 0) {
+            sh.tile_cnt[wv] = 0;
+        }
+        if (cnt) drain_stores();
+        __syncthreads();
+        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+    } else {
+        const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
+        const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+        uint64_t wave_total = 0;
+        for (uint64_t step = wave; step < full_steps; step += n_waves) {
+            RawStep<W0, W1, W2, RPL, U> A;
+            A.template load<NT>(a, step * kStepRows + lane_off);
+            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
+        }
+        if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
+            const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
+            emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
+        }
+        finish_totals<MODE>(a, wave_total);
     }
-    // the partial last step (if any) goes through the guarded evaluator, RPL = 4 layout
-    if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
-        const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
-        emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
-    }
-    clear_super_sums<MODE>(a);
-    finish_totals<MODE>(a, wave_total);
 }
 
 // Chain predicates (AND of possibly complemented leaves, or the negation of one): SGPR planes.
 // A wave keeps the loads of S steps in flight (all S x columns loads are issued, then the steps
 // are evaluated one after the other).
-// Steps per loop iteration (adjacent steps, so the chip-wide access window stays one contiguous range).
-// Measured, fraction of 8 TB/s at 100 M / 1 B rows: a lone 1-byte column wants 2 (COUNT 0.71 / 0.86, IDs
-// 0.61 / 0.69; 1 step: 0.56 / 0.48; 4: 0.72 / 0.86 and 0.60 / 0.65; 8: worse) -- 1 KB per wave and step is
-// too little in flight; from 2 bytes per row on, 1 is best (u16+u8: 0.83 / 0.82 against 0.80 / 0.82 with 2
-// and 0.77 / 0.80 with 4).
+// Steps per wave (adjacent steps, so the chip-wide access window stays one contiguous range).
+// Measured, fraction of 8 TB/s at 100 M / 1 B rows: a lone 1-byte column wants 2 (COUNT 0.71 / 0.86;
+// 1 step: 0.56 / 0.48; 4: 0.72 / 0.86; 8: worse) -- 1 KB per wave and step is too little in flight; from
+// 2 bytes per row on, 1 is best (u16+u8: 0.83 / 0.82 against 0.80 / 0.82 with 2 and 0.77 / 0.80 with 4).
 constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 2 : 1; }
 
 template <int MODE, int W0, int W1, int W2, int S, bool NT, bool VC>
-__global__ __launch_bounds__(kBlock) void eval_chain_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_kernel(const EvalArgs a) {
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
     PQPS_HOIST_KERNARGS(a);
     const uint64_t n_rows = a.n_rows;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint64_t full_steps = n_rows / kStepRows;
     const uint64_t lane_off = lane * RPL;
-    uint64_t wave_total = 0;
-    uint32_t lane_total = 0;                                    // COUNT, one-leaf path: per-lane matches, summed once at the end
     RawStep<W0, W1, W2, RPL, U> A[S];
-    // a wave takes S ADJACENT steps per iteration: the chip-wide access window stays one contiguous range
-    for (uint64_t step0 = wave * S; step0 < full_steps; step0 += n_waves * S) {
+    if constexpr (MODE == MODE_IDS) {
+        constexpr int TS = kWaves * S;                          // a tile = S adjacent steps per wave
+        __shared__ FusedShared sh;
+        zero_other_half(a);
+        const Extent ex = scan_extent<false>(a);
+        const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
+        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
+        const uint64_t step0 = (uint64_t)role.index * TS + (uint64_t)wv * S;
+#pragma unroll
+        for (int i = 0; i < S; i++)
+            if (step0 + i < full_steps) A[i].template load<NT>(a, (step0 + i) * kStepRows + lane_off);      // uniform guard
+        uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i;
-            if (step < full_steps) A[i].template load<NT>(a, step * kStepRows + lane_off);      // uniform guard
+            uint32_t cnt = 0, mbits = 0, lane_total = 0;
+            if (step < full_steps) {
+                A[i].template eval_chain_step<MODE, VC>(a, cnt, mbits, lane_total);
+                tile_step_out(a, sh, wv * S + i, step, cnt, mbits, log2i(RPL), lane);
+            } else if (step < ex.steps) {
+                mbits = eval_step_guarded<false>(a, step * kStepRows, n_rows, 0, lane);
+                cnt = wave_sum_u32(__popc(mbits));
+                tile_step_out(a, sh, wv * S + i, step, cnt, mbits, 2, lane);
+            } else if (lane == 0) {
+                sh.tile_cnt[wv * S + i] = 0;
+            }
+            any |= cnt;
         }
+        if (any) drain_stores();
+        __syncthreads();
+        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+    } else {
+        const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
+        const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+        uint64_t wave_total = 0;
+        uint32_t lane_total = 0;                                // one-leaf path: per-lane matches, summed once at the end
+        // a wave takes S ADJACENT steps per iteration: the chip-wide access window stays one contiguous range
+        for (uint64_t step0 = wave * S; step0 < full_steps; step0 += n_waves * S) {
 #pragma unroll
-        for (int i = 0; i < S; i++) {
-            const uint64_t step = step0 + (uint64_t)i;
-            if (step >= full_steps) break;
-            A[i].template eval_chain_emit<MODE, VC>(a, step, log2i(RPL), lane, wave_total, lane_total);
+            for (int i = 0; i < S; i++) {
+                const uint64_t step = step0 + (uint64_t)i;
+                if (step < full_steps) A[i].template load<NT>(a, step * kStepRows + lane_off);      // uniform guard
+            }
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                const uint64_t step = step0 + (uint64_t)i;
+                if (step >= full_steps) break;
+                uint32_t cnt = 0, mbits = 0;
+                A[i].template eval_chain_step<MODE, VC>(a, cnt, mbits, lane_total);
+                wave_total += cnt;
+            }
         }
-    }
-    if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
-        const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
-        emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
-    }
-    if (MODE != MODE_IDS) wave_total += wave_sum_u32(lane_total);
-    clear_super_sums<MODE>(a);
-    finish_totals<MODE>(a, wave_total);
-}
-
-// ---- K2: group sums ---------------------------------------------------------------------
-// group = 64 steps (64 K rows); supergroup = 64 groups (4 M rows).
-constexpr int kSuperGroups = 64;
-// Device atomics that hit one cache line serialise (~5 ns each, measured), so every
-// supergroup counter lives in its own 4 KiB slot.
-constexpr int kSuperStride = 512;           // in u64
-
-struct SumArgs {
-    const uint32_t *counts;          // [steps]
-    uint64_t steps;
-    uint64_t groups;                 // ceil(steps / 64)
-    uint32_t *group_sum;             // [groups]
-    unsigned long long *super_sum;   // [ceil(groups / 64) * kSuperStride], zeroed by K1
-    uint64_t *base_slot;             // scratch: first output slot of this query
-    const uint64_t *out_count;       // device result counter (read when accumulate)
-    int accumulate;                  // 1: IDs are appended after *out_count (index probes)
-    const uint64_t *range;           // gather: device-side candidate range (else nullptr)
-    uint64_t max_rows;               // gather: the caller's bound on the range length
-};
-
-// Steps K1 evaluated in gather mode (same clamp as eval_generic_kernel).
-__device__ __forceinline__ uint64_t gather_steps(const uint64_t *range, uint64_t max_rows) {
-    const uint64_t b = range[0], e = range[1];
-    uint64_t n = e > b ? e - b : 0;
-    if (n > max_rows) n = max_rows;
-    return (n + kStepRows - 1) / kStepRows;
-}
-
-__global__ __launch_bounds__(kBlock) void group_sum_kernel(const SumArgs a) {
-    const uint32_t lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.base_slot = a.accumulate ? *a.out_count : 0;
-    const uint64_t steps = a.range ? gather_steps(a.range, a.max_rows) : a.steps;
-    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
-    for (uint64_t group = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); group < groups;
-         group += (uint64_t)gridDim.x * kWaves) {
-        const uint64_t step = group * kGroupSteps + lane;
-        const uint32_t c = step < steps ? (a.counts[step] & 0x0FFFFFFFu) : 0u;
-        const uint32_t sum = wave_sum_u32(c);
-        if (lane == 0) {
-            a.group_sum[group] = sum;
-            if (sum) atomicAdd(&a.super_sum[(group / kSuperGroups) * kSuperStride], (unsigned long long)sum);
+        if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
+            const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
+            emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
         }
+        wave_total += wave_sum_u32(lane_total);
+        finish_totals<MODE>(a, wave_total);
     }
 }
 
@@ -853,208 +1255,6 @@ __global__ __launch_bounds__(kBlock) void reduce_totals_kernel(uint64_t *partial
         uint64_t t = 0;
         for (int i = 0; i < kWaves; i++) t += s_wave[i];
         *out_count = t;
-    }
-}
-
-// ---- K3: match bits -> ascending row IDs ---------------------------------------------------
-struct ExpandArgs {
-    const uint16_t *masks;
-    const uint32_t *counts;
-    const uint32_t *group_sum;
-    const unsigned long long *super_sum;
-    const uint64_t *base_slot;
-    uint64_t *out_count;             // written by the workgroup that owns the last group
-    uint64_t steps;
-    uint64_t groups;
-    uint32_t *out_ids;
-    uint64_t out_cap;
-    const uint32_t *cand;            // gather: candidate list
-    const uint64_t *range;
-    uint64_t max_rows;               // gather: the caller's bound on the range length
-    uint32_t id_base;
-    uint32_t gather;
-    uint64_t wave_groups_min;        // from this many groups on: one group per WAVE (see expand_kernel)
-};
-
-constexpr int kStageIds = kStepRows;        // a step yields at most 1024 IDs
-
-// One step: K1 left 16 match bits per lane in its load layout (bit p of lane l <-> row
-// (p / RPL) * 64 * RPL + l * RPL + p % RPL).  First bring them into ROW order -- lane d gets the
-// bits of rows 16d .. 16d+15, which sit in 16/RPL source lanes -- then one wave scan gives every
-// lane its output rank; IDs are staged in LDS and written out with fully coalesced stores.
-template <int RL>                                               // log2(RPL): 2, 3 or 4
-__device__ __forceinline__ void expand_step(const ExpandArgs &a, uint64_t step, uint32_t m16, uint32_t count,
-                                            uint64_t out_off, uint64_t begin, uint32_t lane, uint32_t *stage) {
-    constexpr uint32_t RPL = 1u << RL, S = 16u / RPL;              // S source lanes per destination lane
-    uint32_t word;
-    if constexpr (S == 1) {
-        word = m16;
-    } else {
-        constexpr uint32_t LPC = 64u / S;                           // destination lanes per chunk
-        const uint32_t u = lane / LPC, first = S * (lane % LPC);
-        word = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < S; q++) {
-            const uint32_t src = (uint32_t)__shfl((int)m16, (int)(first + q), 64);
-            word |= ((src >> (RPL * u)) & ((1u << RPL) - 1u)) << (RPL * q);
-        }
-    }
-    const uint32_t cnt = __popc(word);
-    const uint32_t incl = wave_incl_scan_u32(cnt);
-    uint32_t pos = incl - cnt;
-    const uint32_t r0 = (uint32_t)(step * kStepRows) + lane * 16u;
-    if (a.gather) {                                                 // uniform
-        // candidate numbers of the set bits, all requested before any is used (one memory latency per
-        // step, not one per ID); a set bit implies the row lies inside the probed range
-        uint32_t c[16];
-#pragma unroll
-        for (uint32_t j = 0; j < 16; j++) c[j] = ((word >> j) & 1u) ? a.cand[begin + r0 + j] : 0u;
-#pragma unroll
-        for (uint32_t j = 0; j < 16; j++)
-            if ((word >> j) & 1u) stage[pos++] = c[j] + a.id_base;
-    } else {
-        while (word) {                                              // set bits only, ascending rows
-            const uint32_t j = (uint32_t)__builtin_ctz(word);
-            word &= word - 1;
-            stage[pos++] = r0 + j + a.id_base;
-        }
-    }
-    // same wave wrote and reads: DS operations of one wave complete in order; the asm only
-    // stops the compiler from moving the reads above the writes
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (uint32_t k = lane; k < count; k += 64) {
-        const uint64_t o = out_off + k;
-        if (o < a.out_cap) a.out_ids[o] = stage[k];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // reads done before the next step overwrites
-}
-
-__device__ __forceinline__ void expand_step_any(const ExpandArgs &a, uint64_t step, uint32_t m16, uint32_t rpl_log2,
-                                                uint32_t count, uint64_t out_off, uint64_t begin, uint32_t lane,
-                                                uint32_t *stage) {
-    switch (rpl_log2) {                                             // uniform
-    case 2: expand_step<2>(a, step, m16, count, out_off, begin, lane, stage); break;
-    case 3: expand_step<3>(a, step, m16, count, out_off, begin, lane, stage); break;
-    default: expand_step<4>(a, step, m16, count, out_off, begin, lane, stage); break;
-    }
-}
-
-// Workgroup per group of 64 steps.  Its first output slot is computed on the fly from the
-// supergroup sums (<= a few hundred values) and the <= 63 earlier group sums of its own
-// supergroup, so no serial scan kernel is needed.  The 4 waves then share the non-empty steps
-// round-robin and fetch the match bits of up to 4 steps at a time.
-__global__ __launch_bounds__(kBlock) void expand_kernel(const ExpandArgs a) {
-    __shared__ uint32_t s_part[kWaves];
-    __shared__ uint32_t s_stage[kWaves][kStageIds];
-    __shared__ uint16_t s_mask[kWaves][kGroupSteps / kWaves][64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t begin = a.gather ? a.range[0] : 0;
-    const uint64_t base0 = *a.base_slot;
-    const uint64_t steps = a.gather ? gather_steps(a.range, a.max_rows) : a.steps;
-    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
-    if (groups >= a.wave_groups_min) {                                // uniform for the grid
-        // very many groups (>= 0.5 G rows): a group per WAVE.  The per-group chain of dependent loads
-        // (sums in front -> counts -> match words -> IDs) is latency, not work; with four times as
-        // many groups in flight the same chip finishes in a quarter of the rounds.  No barriers.
-        for (uint64_t group = (uint64_t)blockIdx.x * kWaves + wave; group < groups; group += (uint64_t)gridDim.x * kWaves) {
-            const uint64_t my_step = group * kGroupSteps + lane;
-            const uint32_t cw = my_step < steps ? a.counts[my_step] : 0u;
-            const uint64_t sg = group / kSuperGroups, g_in = group % kSuperGroups;
-            uint32_t psum = 0;
-            for (uint64_t j = lane; j < sg; j += 256) {              // four independent loads per trip
-                const uint64_t j1 = j + 64, j2 = j + 128, j3 = j + 192;
-                const unsigned long long s0 = a.super_sum[j * kSuperStride];
-                const unsigned long long s1 = j1 < sg ? a.super_sum[j1 * kSuperStride] : 0ull;
-                const unsigned long long s2 = j2 < sg ? a.super_sum[j2 * kSuperStride] : 0ull;
-                const unsigned long long s3 = j3 < sg ? a.super_sum[j3 * kSuperStride] : 0ull;
-                psum += (uint32_t)s0 + (uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3;
-            }
-            if (lane < g_in) psum += a.group_sum[sg * kSuperGroups + lane];
-            const uint32_t my_cnt = cw & 0x0FFFFFFFu;
-            const uint64_t nonempty = __ballot(my_cnt != 0);
-            const bool last_group = group + 1 == groups;
-            if (nonempty == 0 && !last_group) continue;             // uniform for the wave
-            const uint64_t group_off = base0 + wave_sum_u32(psum);
-            const uint32_t incl = wave_incl_scan_u32(my_cnt);
-            const uint64_t my_off = group_off + (incl - my_cnt);
-            if (last_group && lane == 63) *a.out_count = group_off + incl;
-            const uint16_t *gmask = a.masks + group * kGroupSteps * 64 + lane;
-            for (uint32_t c = 0; c < kGroupSteps; c += 16) {          // 16 consecutive steps at a time
-                const uint32_t bits = (uint32_t)(nonempty >> c) & 0xFFFFu;
-                if (!bits) continue;
-                uint32_t mreg[16];
-#pragma unroll
-                for (uint32_t i = 0; i < 16; i++) {
-                    mreg[i] = 0;
-                    if ((bits >> i) & 1u) mreg[i] = gmask[(size_t)(c + i) * 64];                          // uniform branch
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < 16; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                for (uint32_t i = 0; i < 16; i++) {
-                    if (!((bits >> i) & 1u)) continue;
-                    const int sidx = (int)(c + i);
-                    const uint64_t step_off = readlane_u64(my_off, sidx);           // sidx is wave-uniform: v_readlane, no LDS crossbar
-                    const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
-                    expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
-                                    cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
-                }
-            }
-        }
-        return;
-    }
-    // few groups (a narrow index probe, a small table): split each over `parts` workgroups, every one
-    // expanding 64 / parts of the group's steps, so that the work still spreads over the chip
-    const uint32_t parts = groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u);
-    const uint32_t slots = (kGroupSteps / kWaves) / parts;            // step slots per wave: 16, 4 or 1
-    for (uint64_t v = blockIdx.x; v < groups * parts; v += gridDim.x) {
-        const uint64_t group = v / parts;
-        const uint32_t part = (uint32_t)(v % parts);
-        // (1) counts of the 64 steps (every wave loads the same 256 bytes) + the sums in front
-        const uint64_t my_step = group * kGroupSteps + lane;
-        const uint32_t cw = my_step < steps ? a.counts[my_step] : 0u;
-        const uint64_t sg = group / kSuperGroups, g_in = group % kSuperGroups;
-        uint32_t psum = 0;                                          // < 2^32: row IDs are u32
-        for (uint64_t j = tid; j < sg; j += kBlock) psum += (uint32_t)a.super_sum[j * kSuperStride];
-        if (tid < g_in) psum += a.group_sum[sg * kSuperGroups + tid];
-        const uint32_t my_cnt = cw & 0x0FFFFFFFu;
-        const uint64_t nonempty = __ballot(my_cnt != 0);
-        const bool last_group = group + 1 == groups;
-        if (nonempty == 0 && !last_group) continue;                 // uniform for the workgroup
-        // (2) matches before this group
-        psum = wave_sum_u32(psum);
-        __syncthreads();                                            // previous iteration done with s_part
-        if (lane == 0) s_part[wave] = psum;
-        __syncthreads();
-        uint64_t group_off = base0;
-#pragma unroll
-        for (int i = 0; i < kWaves; i++) group_off += s_part[i];
-        // (3) exclusive prefix of the step counts inside the group
-        const uint32_t incl = wave_incl_scan_u32(my_cnt);
-        const uint64_t my_off = group_off + (incl - my_cnt);
-        if (last_group && part == 0 && wave == 0 && lane == 63) *a.out_count = group_off + incl;
-        // (4) wave w owns steps w, w+4, ... of the group (slot i <-> step w + 4i); this workgroup takes
-        // the slots [part * slots, (part + 1) * slots).  All their match-bit words are requested at
-        // once (one memory latency for up to 16 steps), parked in LDS, then expanded.
-        const uint16_t *gmask = a.masks + (group * kGroupSteps + wave) * 64 + lane;
-        const uint32_t slot0 = part * slots, slot1 = slot0 + slots;
-        uint32_t mreg[kGroupSteps / kWaves];
-#pragma unroll
-        for (uint32_t i = 0; i < kGroupSteps / kWaves; i++) {
-            mreg[i] = 0;
-            if (i >= slot0 && i < slot1 && ((nonempty >> (wave + kWaves * i)) & 1ull)) mreg[i] = gmask[(size_t)i * kWaves * 64];   // uniform branch
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < kGroupSteps / kWaves; i++) s_mask[wave][i][lane] = (uint16_t)mreg[i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (uint32_t i = slot0; i < slot1; i++) {
-            const int sidx = (int)(wave + kWaves * i);
-            if (!((nonempty >> sidx) & 1ull)) continue;
-            const uint64_t step_off = readlane_u64(my_off, sidx);           // sidx is wave-uniform: v_readlane, no LDS crossbar
-            const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
-            expand_step_any(a, group * kGroupSteps + (uint64_t)sidx, s_mask[wave][i][lane], cwi >> 28,
-                            cwi & 0x0FFFFFFFu, step_off, begin, lane, s_stage[wave]);
-        }
     }
 }
 

@@ -289,20 +289,28 @@ struct pqps_ctx {
     int device;
     int compute_units;
     hipStream_t stream;
-    // filter scratch, grown on demand: match bits, step counts, group / supergroup sums
+    // filter scratch, grown on demand
     uint64_t scratch_steps;     // capacity in steps of 1024 rows
-    uint16_t *masks;
-    uint32_t *counts;
-    uint32_t *group_sum;        // [groups]
-    unsigned long long *super_sum;   // [supergroups]
-    uint64_t *base_slot;        // first output slot of the running query
-    uint64_t *partials;         // workgroup totals of K1 (COUNT / FLAGS modes)
+    uint16_t *masks;            // [steps][64] match words
+    uint32_t *counts;           // [steps] step counts; all zero between queries
+    // hand-off words of the ID-output launch: two halves used alternately; a query zeroes the half the
+    // previous one used.  Per half: ctl[kCtlWords] u32 | sword[supers] u64 | gword[groups] u64 | deferred[groups] u32
+    char *hand;
+    size_t hand_half_bytes;
+    uint64_t hand_groups, hand_supers;   // capacities
+    int parity;                 // half the next ID query uses
+    uint64_t dirty_groups[2];   // groups the last query on each half can have written
+    uint64_t *base_slot;        // gather: first output slot of the running query
+    uint64_t *partials;         // workgroup totals of the scan (COUNT / FLAGS modes)
+    uint32_t *status_host;      // mapped host word: set by a kernel whose recovery pass gave up
+    uint32_t *status_dev;       // its device address
     void *sort_tmp;
     size_t sort_tmp_bytes;
-    // optional per-launch timing (bench.py roofline): K1 alone and K1..K3
+    // optional per-launch timing (bench.py roofline)
     bool timing;
     int timed;                  // launches recorded since the last reset
     hipEvent_t *ev_start, *ev_eval, *ev_stop;
+    bool *stop_is_eval;         // ID output is one launch: its stop event is the end of the query
 };
 
 namespace {
@@ -312,14 +320,15 @@ hipStream_t pick_stream(pqps_ctx *ctx, void *stream) { return stream ? (hipStrea
 void free_scratch(pqps_ctx *ctx) {
     if (ctx->masks) (void)hipFree(ctx->masks);
     if (ctx->counts) (void)hipFree(ctx->counts);
-    if (ctx->group_sum) (void)hipFree(ctx->group_sum);
-    if (ctx->super_sum) (void)hipFree(ctx->super_sum);
+    if (ctx->hand) (void)hipFree(ctx->hand);
     if (ctx->base_slot) (void)hipFree(ctx->base_slot);
     if (ctx->partials) (void)hipFree(ctx->partials);
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = nullptr; ctx->super_sum = nullptr;
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->hand = nullptr;
     ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->scratch_steps = 0;
 }
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     if (ctx->scratch_steps >= steps && ctx->masks) return PQPS_OK;
@@ -329,13 +338,33 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     const uint64_t supers = (groups + kSuperGroups - 1) / kSuperGroups;
     HIP_TRY(hipMalloc((void **)&ctx->masks, cap * 64 * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->group_sum, groups * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&ctx->super_sum, supers * kSuperStride * sizeof(unsigned long long)));
+    ctx->hand_groups = groups;
+    ctx->hand_supers = supers;
+    ctx->hand_half_bytes = align256(kCtlWords * 4) + align256(supers * 8) + align256(groups * 8) + align256(groups * 4);
+    HIP_TRY(hipMalloc((void **)&ctx->hand, 2 * ctx->hand_half_bytes));
     HIP_TRY(hipMalloc((void **)&ctx->base_slot, 64));
     HIP_TRY(hipMalloc((void **)&ctx->partials, kPartialSlots * sizeof(uint64_t)));
+    // the scan relies on: step counts all zero, both halves of the hand-off words zero
+    HIP_TRY(hipMemset(ctx->counts, 0, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ctx->hand, 0, 2 * ctx->hand_half_bytes));
     HIP_TRY(hipMemset(ctx->partials, 0, kPartialSlots * sizeof(uint64_t)));
+    ctx->parity = 0;
+    ctx->dirty_groups[0] = ctx->dirty_groups[1] = 0;
     ctx->scratch_steps = cap;
     return PQPS_OK;
+}
+
+// Pointers into one half of the hand-off block.
+struct HandHalf { uint32_t *ctl; uint64_t *sword; uint64_t *gword; uint32_t *deferred; };
+
+HandHalf hand_half(const pqps_ctx *ctx, int half) {
+    char *p = ctx->hand + (size_t)half * ctx->hand_half_bytes;
+    HandHalf h;
+    h.ctl = (uint32_t *)p;                 p += align256(kCtlWords * 4);
+    h.sword = (uint64_t *)p;               p += align256(ctx->hand_supers * 8);
+    h.gword = (uint64_t *)p;               p += align256(ctx->hand_groups * 8);
+    h.deferred = (uint32_t *)p;
+    return h;
 }
 
 int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
@@ -412,11 +441,15 @@ void fill_args(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, const pqps
 typedef void (*eval_fn)(const EvalArgs);
 
 // every non-increasing (W0, W1, W2) from {8,4,2,1}, W = 0 marks an unused slot
+#ifdef PQPS_DEV_SHAPES   /* development builds: the bench shapes only (compiles in a fraction of the time) */
+#define PQPS_FOR_EACH_SHAPE(X) X(4,0,0) X(2,0,0) X(1,0,0) X(4,1,0) X(2,1,0) X(4,4,4)
+#else
 #define PQPS_FOR_EACH_SHAPE(X) \
     X(8,0,0) X(4,0,0) X(2,0,0) X(1,0,0) \
     X(8,8,0) X(8,4,0) X(8,2,0) X(8,1,0) X(4,4,0) X(4,2,0) X(4,1,0) X(2,2,0) X(2,1,0) X(1,1,0) \
     X(8,8,8) X(8,8,4) X(8,8,2) X(8,8,1) X(8,4,4) X(8,4,2) X(8,4,1) X(8,2,2) X(8,2,1) X(8,1,1) \
     X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
+#endif
 
 // chain kernels exist with 1 step per iteration and (narrow shapes) with several
 // the vector-unit variant (VC) exists for the single-column shapes only
@@ -501,17 +534,34 @@ uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps, bool streaming, uint32_t steps
     return (uint32_t)(g ? g : 1);
 }
 
-// K1 (+ K2 + K3 for ID output).  `rows` = scan rows or the gather upper bound.
+// Placement of the expander workgroups: `lag` groups behind the scan tiles of their group -- a little more than
+// the groups the chip has in flight (8 workgroups per CU), so that an expander normally finds everything it
+// needs already there.  (Speed only: an expander checks and waits.)
+uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
+    static const char *env = getenv("PQPS_EXPAND_LAG");
+    if (env) return (uint32_t)strtoul(env, nullptr, 10);
+    return (uint32_t)ctx->compute_units * 10u / (tiles_per_group + 1u);
+}
+
+uint32_t expand_spin_limit() {
+    static const char *env = getenv("PQPS_EXPAND_SPIN_LIMIT");      // 0: an expander that is early gives up at once (tests the recovery pass)
+    return env ? (uint32_t)strtoul(env, nullptr, 10) : (1u << 16);
+}
+
+// The filter.  `rows` = scan rows or the gather upper bound.
+//   COUNT / FLAGS: the scan kernel + a one-workgroup reduction of the workgroup totals.
+//   ID output:     ONE launch -- scan tiles and, `lag` groups behind them in the grid, the expander
+//                  workgroups that turn match words into row IDs (filter_kernels.hpp).
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
-               hipEvent_t done = nullptr, hipStream_t compact = nullptr, hipEvent_t k1_done = nullptr) {
+               hipEvent_t done = nullptr, hipStream_t tail = nullptr, hipEvent_t scan_done = nullptr) {
     // `done` (optional) becomes ready when the last kernel of this query has finished.  It rides on
     // that kernel's own dispatch packet: a separate hipEventRecord would put a barrier packet behind
     // it and cost the NEXT query on this stream ~7 us of idle queue.
-    // `compact` (optional, ID output): K2 and K3 run on that stream behind K1's own completion event
-    // `k1_done`, so that the caller's stream is free for the next query's K1 at once -- the ~12 us of
-    // latency-bound compaction then hide under the next bandwidth-bound scan (the caller gives every
-    // query in flight its own ctx = its own scratch).
+    // `tail` (optional, ID output): the expanders of the last `lag` groups -- the only part of the query that
+    // cannot run in the shadow of the scan -- are a second launch of the same kernel on that stream, behind
+    // the first one's completion event `scan_done`; the caller's stream is free for the next query's scan at
+    // once (the caller gives every query in flight its own ctx = its own scratch).
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
@@ -519,62 +569,69 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.masks = ctx->masks;
     a.counts = ctx->counts;
     a.partials = ctx->partials;
-    a.super_sum = ctx->super_sum;
-    a.n_super = (uint32_t)((groups + kSuperGroups - 1) / kSuperGroups);
-    const uint32_t grid = eval_grid(ctx, steps, a.streaming != 0, a.steps_per_iter);
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
-    const bool split = compact != nullptr && compact != s && mode == MODE_IDS && (timed || k1_done != nullptr);
-    if (timed || split) {
-        // the events are attached to the dispatch itself: they carry the kernel's own begin / end
-        // timestamps (what rocprofv3 --kernel-trace reports), not the queueing around it
-        hipEvent_t k1_stop = timed ? ctx->ev_eval[ctx->timed] : k1_done;
-        hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, k1_stop, 0, a);
-        HIP_TRY(hipGetLastError());
-        if (split) { HIP_TRY(hipStreamWaitEvent(compact, k1_stop, 0)); s = compact; }   // everything below runs there
-    } else {
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
-        HIP_TRY(hipGetLastError());
-    }
     if (mode != MODE_IDS) {
+        const uint32_t grid = eval_grid(ctx, steps, a.streaming != 0, a.steps_per_iter);
+        if (timed) hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, ctx->ev_start[ctx->timed], ctx->ev_eval[ctx->timed], 0, a);
+        else hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
+        HIP_TRY(hipGetLastError());
         if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, out_count);
         else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, out_count);
         HIP_TRY(hipGetLastError());
-    } else {
-        SumArgs sa;
-        sa.counts = ctx->counts; sa.steps = steps; sa.groups = groups;
-        sa.group_sum = ctx->group_sum; sa.super_sum = ctx->super_sum; sa.base_slot = ctx->base_slot;
-        sa.out_count = out_count; sa.accumulate = gather ? 1 : 0;
-        sa.range = gather ? a.range : nullptr; sa.max_rows = rows;
-        uint64_t sum_blocks = (groups + kWaves - 1) / kWaves;
-        if (sum_blocks > 2048) sum_blocks = 2048;
-        hipLaunchKernelGGL(group_sum_kernel, dim3((uint32_t)(sum_blocks ? sum_blocks : 1)), dim3(kBlock), 0, s, sa);
+        if (timed) { ctx->stop_is_eval[ctx->timed] = false; HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
+        return PQPS_OK;
+    }
+    if (groups == 0) {
+        // no rows at all: the count is the base (0, or unchanged when appending)
+        if (!gather) HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
+        if (tail && tail != s && scan_done) {                       // what follows on `tail` still comes after this query
+            HIP_TRY(hipEventRecord(scan_done, s));
+            HIP_TRY(hipStreamWaitEvent(tail, scan_done, 0));
+            if (done) HIP_TRY(hipEventRecord(done, tail));
+        } else if (done) {
+            HIP_TRY(hipEventRecord(done, s));
+        }
+        return PQPS_OK;
+    }
+    const int half = ctx->parity;
+    ctx->parity ^= 1;
+    const HandHalf mine = hand_half(ctx, half), other = hand_half(ctx, half ^ 1);
+    a.gword = mine.gword; a.sword = mine.sword; a.ctl = mine.ctl; a.deferred = mine.deferred;
+    a.zgword = other.gword; a.zsword = other.sword; a.zctl = other.ctl; a.zdeferred = other.deferred;
+    a.zero_groups = ctx->dirty_groups[half ^ 1];
+    ctx->dirty_groups[half ^ 1] = 0;
+    ctx->dirty_groups[half] = groups;
+    a.base_slot = ctx->base_slot;
+    a.status = ctx->status_dev;
+    a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
+    a.id_base = id_base;
+    a.accumulate = gather ? 1u : 0u;
+    const uint32_t tiles_per_group = (uint32_t)kGroupSteps / ((uint32_t)kWaves * (a.steps_per_iter ? a.steps_per_iter : 1u));
+    a.lag = expand_lag(ctx, tiles_per_group);
+    a.spin_limit = expand_spin_limit();
+    a.block_base = 0;
+    const uint64_t main_blocks = groups * (tiles_per_group + 1), lag = a.lag < groups ? a.lag : groups;
+    if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
+    const bool split = tail != nullptr && tail != s && scan_done != nullptr;
+    if (!split) {
+        hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
+        if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
+        else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag)), dim3(kBlock), 0, s, a);
         HIP_TRY(hipGetLastError());
-        ExpandArgs ea;
-        ea.masks = ctx->masks; ea.counts = ctx->counts; ea.group_sum = ctx->group_sum; ea.super_sum = ctx->super_sum;
-        ea.base_slot = ctx->base_slot; ea.out_count = out_count;
-        ea.steps = steps; ea.groups = groups; ea.out_ids = out_ids; ea.out_cap = out_cap;
-        ea.cand = a.cand; ea.range = a.range; ea.max_rows = rows; ea.id_base = id_base; ea.gather = gather ? 1u : 0u;
-        if (groups) {
-            const uint64_t cap = (uint64_t)ctx->compute_units * 32;
-            // few groups are split over up to 16 workgroups each (expand_kernel derives `parts` from the
-            // group count it sees on the device, which in gather mode can be smaller than this bound)
-            static const char *wg_env = getenv("PQPS_K3_WAVE_GROUPS");
-            ea.wave_groups_min = wg_env ? strtoull(wg_env, nullptr, 10) : 8192;
-            // (in gather mode the device may see fewer groups than this bound and pick another mode:
-            // every mode loops over its work with the grid it is given)
-            const uint64_t vgroups = groups >= ea.wave_groups_min ? (groups + kWaves - 1) / kWaves
-                                   : groups * (groups >= 512 ? 1u : (groups >= 128 ? 4u : 16u));
-            const dim3 eg((uint32_t)(vgroups < cap ? vgroups : cap));
-            if (done) hipExtLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, nullptr, done, 0, ea);
-            else hipLaunchKernelGGL(expand_kernel, eg, dim3(kBlock), 0, s, ea);
-            HIP_TRY(hipGetLastError());
-        } else {
-            // no rows at all: the count is the base (0, or unchanged when appending)
-            if (!gather) HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
+        if (timed) {
+            ctx->stop_is_eval[ctx->timed] = true;
+            ctx->timed++;
             if (done) HIP_TRY(hipEventRecord(done, s));
         }
+        return PQPS_OK;
     }
-    if (timed) { HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
+    hipExtLaunchKernelGGL(k1, dim3((uint32_t)main_blocks), dim3(kBlock), 0, s, nullptr, scan_done, 0, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamWaitEvent(tail, scan_done, 0));
+    a.block_base = main_blocks;
+    if (done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)lag), dim3(kBlock), 0, tail, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k1, dim3((uint32_t)lag), dim3(kBlock), 0, tail, a);
+    HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }
 
@@ -607,19 +664,26 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->scratch_steps = 0;
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->group_sum = nullptr; ctx->super_sum = nullptr;
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->hand = nullptr;
     ctx->base_slot = nullptr; ctx->partials = nullptr;
+    ctx->status_host = nullptr; ctx->status_dev = nullptr;
+    ctx->parity = 0; ctx->dirty_groups[0] = ctx->dirty_groups[1] = 0;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
     ctx->timed = 0;
     ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
+    ctx->stop_is_eval = nullptr;
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete ctx; return fail(PQPS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    // sticky status word in mapped host memory: a kernel whose recovery pass gave up sets it, pqps_ctx_sync reports it
+    se = hipHostMalloc((void **)&ctx->status_host, 64, hipHostMallocMapped);
+    if (se == hipSuccess) { *ctx->status_host = 0; se = hipHostGetDevicePointer((void **)&ctx->status_dev, ctx->status_host, 0); }
+    if (se != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(PQPS_EHIP, "status word: %s", hipGetErrorString(se)); }
     hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(1), 0, ctx->stream);
     se = hipGetLastError();
     if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);
-    if (se != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(PQPS_EHIP, "first kernel launch: %s", hipGetErrorString(se)); }
+    if (se != hipSuccess) { (void)hipHostFree(ctx->status_host); (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(PQPS_EHIP, "first kernel launch: %s", hipGetErrorString(se)); }
     *out = ctx;
     return PQPS_OK;
 }
@@ -657,7 +721,9 @@ void pqps_ctx_destroy(pqps_ctx *ctx) {
         delete[] ctx->ev_start;
         delete[] ctx->ev_eval;
         delete[] ctx->ev_stop;
+        delete[] ctx->stop_is_eval;
     }
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -668,7 +734,8 @@ int pqps_ctx_set_timing(pqps_ctx *ctx, int enable) {
         ctx->ev_start = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
         ctx->ev_eval = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
         ctx->ev_stop = new (std::nothrow) hipEvent_t[kMaxTimedLaunches];
-        if (!ctx->ev_start || !ctx->ev_eval || !ctx->ev_stop) return fail(PQPS_ENOMEM, "out of host memory");
+        ctx->stop_is_eval = new (std::nothrow) bool[kMaxTimedLaunches]();
+        if (!ctx->ev_start || !ctx->ev_eval || !ctx->ev_stop || !ctx->stop_is_eval) return fail(PQPS_ENOMEM, "out of host memory");
         for (int i = 0; i < kMaxTimedLaunches; i++) {
             HIP_TRY(hipEventCreate(&ctx->ev_start[i]));
             HIP_TRY(hipEventCreate(&ctx->ev_eval[i]));
@@ -684,11 +751,12 @@ int pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *
     if (!ctx || !eval_ms || !total_ms || !launches) return fail(PQPS_EINVAL, "NULL argument");
     double sum_eval = 0.0, sum_total = 0.0;
     for (int i = 0; i < ctx->timed; i++) {
-        HIP_TRY(hipEventSynchronize(ctx->ev_stop[i]));
+        hipEvent_t stop = ctx->stop_is_eval[i] ? ctx->ev_eval[i] : ctx->ev_stop[i];
+        HIP_TRY(hipEventSynchronize(stop));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_eval[i]));
         sum_eval += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[i], ctx->ev_stop[i]));
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start[i], stop));
         sum_total += ms;
     }
     *eval_ms = sum_eval;
@@ -701,6 +769,9 @@ int pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *
 int pqps_ctx_sync(pqps_ctx *ctx, void *stream) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(pick_stream(ctx, stream)));
+    if (*(volatile uint32_t *)ctx->status_host != 0)
+        return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this context are incomplete",
+                    *(volatile uint32_t *)ctx->status_host);
     return PQPS_OK;
 }
 
@@ -790,6 +861,7 @@ int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
     a.out_flags = out_flags;
+    set_streaming(a, cols, n_cols, n_rows);                      // load policy + grid of a scan that outgrows the Infinity Cache
     return run_filter(ctx, a.streaming ? eval_generic_kernel<MODE_FLAGS, false, true> : eval_generic_kernel<MODE_FLAGS, false, false>, a, n_rows, MODE_FLAGS, false,
                       0, nullptr, 0, out_count, s);
 }
