@@ -52,19 +52,17 @@ struct EvalArgs {
     uint64_t truth;
     uint64_t n_rows;                 // scan: rows; gather: caller's upper bound (range is on the device)
     uint16_t *masks;                 // [steps][64] match bits of every lane
-    uint32_t *counts;                // [steps]     matches | log2(RPL) << 28; all zero between queries
+    uint32_t *counts;                // [steps]     epoch << 16 | log2(RPL) << 11 | matches
     uint8_t *out_flags;              // MODE_FLAGS
     uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
     const uint32_t *cand;            // gather: candidate row numbers
     const uint64_t *range;           // gather: [begin, end) into cand, device resident
-    // ---- ID output: hand-off words of this query (one half of the ping-pong pair) and the result ----
-    uint64_t *gword;                 // [groups]  steps arrived << 48 | matches
-    uint64_t *sword;                 // [supers]  groups forwarded << 48 | matches
-    uint32_t *ctl;                   // [kCtlWords] expanders past their wait, deferred groups
-    uint32_t *deferred;              // [groups]  1 = left to the recovery pass, | 2 = already forwarded
-    uint64_t *zgword, *zsword;       // the other half: zeroed here for the query after this one
-    uint32_t *zctl, *zdeferred;
-    uint64_t zero_groups;            // ... as far as its last query can have written
+    // ---- ID output: hand-off words (epoch-tagged: valid when the tag is this query's) and the result ----
+    uint64_t *gsum;                  // [groups]  epoch << 48 | matches of the group
+    uint64_t *ssum;                  // [supers]  epoch << 48 | matches of the supergroup
+    uint32_t *deferred;              // [groups]  epoch << 16 | 1 = given up, left to the recovery pass | 2 = its sum is published
+    uint32_t *ctl;                   // [kCtlWords] expanders past their wait, deferred groups (zero at launch)
+    uint32_t *zctl;                  // the other half of the ctl pair: zeroed here for the query after this one
     uint64_t *base_slot;             // gather: first output slot (= *out_count when the launch began)
     uint32_t *status;                // sticky error word of the context (a wait that never ended)
     uint32_t *out_ids;
@@ -73,8 +71,10 @@ struct EvalArgs {
     uint64_t block_base;             // added to blockIdx.x (the trailing expanders can be a launch of their own)
     uint32_t id_base;
     uint32_t lag;                    // groups between a group's scan tiles and its expander in the grid
+    uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
     uint32_t accumulate;             // gather: append behind *out_count
+    uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
     uint32_t n_cols;
     uint32_t n_leaves;
     uint32_t negmask;
@@ -385,6 +385,18 @@ template <bool NT> __device__ __forceinline__ uint32_t ld_x1(const void *p) {
     else return *(const uint32_t *)p;
 }
 
+// Match bits of rows at or past n_rows never count.  Bit p of lane l <-> row step_row0 + (p / RPL) * 64 * RPL + l * RPL + p % RPL.
+// (The partial last step of a scan is evaluated like a full one -- column buffers are readable up to the next
+// multiple of 1024 rows, see pqps_filter_scan -- and trimmed with this.)
+template <int RPL>
+__device__ __forceinline__ uint32_t rows_below(uint64_t step_row0, uint64_t n_rows, uint32_t lane) {
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < 16; p++)
+        if (step_row0 + (uint64_t)(p / RPL) * 64 * RPL + (uint64_t)lane * RPL + p % RPL < n_rows) m |= 1u << p;
+    return m;
+}
+
 // ---- generic evaluators (any number of columns / leaves), RPL = 4 -----------------------
 // Fast path: all 1024 rows of the step exist and are contiguous.
 template <bool NT>
@@ -487,21 +499,41 @@ __device__ __forceinline__ uint32_t eval_step_guarded(const EvalArgs &a, uint64_
 }
 
 // ---- ID output: tiles, groups, and the hand-off between scan and expand workgroups ------------------
-// group = 64 steps (64 K rows); supergroup = 64 groups (4 M rows).  A hand-off word = arrivals << 48 | matches.
+// group = 64 steps (64 K rows); supergroup = 64 groups (4 M rows).  Nothing in the hand-off is an atomic
+// read-modify-write (agent-scope atomics that share a 128-byte line serialise at ~5 ns each -- 24 k of them cost
+// more than the 100 M-row scan they signal for): every shared word is written per query by one lane with a
+// write-through store and carries the query's EPOCH, so it is valid exactly when its tag matches -- no word
+// needs zeroing between queries.
+//   counts[step]  epoch << 16 | log2(RPL) << 11 | matches   written by the step's scan tile
+//   gsum[group]   epoch << 48 | matches of the group        written by a scan tile `sum_lag` groups further on (sum duty)
+//   ssum[super]   epoch << 48 | matches of the supergroup   written by a scan tile 2 * sum_lag groups past its end
+// (the last groups of a table have no tile that far behind them: there the expanders write the words themselves).
+// What lies in front of group g = the ssum of every supergroup before its own + the gsum of the earlier groups
+// of its own: two dense arrays, read whole in one round of loads.  No word depends on another group's position
+// in the output, so no chain of waits forms, and an expander placed 3 * sum_lag groups behind its group's tiles
+// finds everything it needs at its first look.
 constexpr int kSuperGroups = 64;
-constexpr int kArrShift = 48;
-constexpr uint64_t kSumMask = (1ull << kArrShift) - 1ull;
-constexpr int kCtlWords = 16;               // ctl[0]: expanders past their wait; ctl[1]: groups left to the recovery pass
-constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches writes its IDs lane by lane
+// ctl: the only words with atomic read-modify-writes, none of them on a path anything waits for.  An expander that
+// has finished adds 1 to the shard of its group (64 shards, a 128-byte line each: neighbouring groups finish at the
+// same time, and atomics that share a line serialise); the last of a shard adds 1 to the top word; the last of those
+// is the last expander of the launch -- the one that looks whether any group was given up on.
+constexpr int kCtlShards = 64, kCtlStride = 32;                     // u32 words per line
+constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1) * kCtlStride;
+constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
+constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
+constexpr uint32_t kStageRing = 256;        // >= kDirectIds + 63
 constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
+constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
+constexpr int kRplShift = 11, kEpochShift = 16, kWordEpochShift = 48;
+constexpr uint64_t kWordMask = (1ull << kWordEpochShift) - 1ull;
 
-struct FusedShared {
-    uint16_t mask[kWaves][kGroupSteps / kWaves][64];   // expander: match words of a wave's 16 steps
-    uint32_t counts[kGroupSteps];                       // expander: step counts of the group
+struct alignas(16) FusedShared {
+    uint16_t mask[kWaves][kGroupSteps / kWaves][64];   // expander waves: match words of 16 steps at a time
+    uint32_t stage[kWaves][kStageRing];                // expander waves: row IDs on their way out, 64 to a store
+    uint32_t counts[kGroupSteps];                       // trailing expander: step counts of the group, from its leader wave
+    uint64_t group_off;                                 //   ... and the group's first output slot
+    uint32_t state;                                     //   ... 1 = expand now, 0 = deferred
     uint32_t tile_cnt[16];                              // scan: step counts of the tile
-    uint64_t group_off;                                 // expander: first output slot of the group
-    uint32_t state;                                     // expander: 1 = expand now, 0 = deferred
-    uint32_t recover;                                   // expander: this workgroup runs the recovery pass
 };
 
 // What this launch covers: a scan of n_rows rows, or (gather) the device-side candidate range clamped
@@ -525,34 +557,44 @@ __device__ __forceinline__ Extent scan_extent(const EvalArgs &a) {
     return e;
 }
 
-// Grid layout (TPG tiles per group): the tiles of group q are followed by the expander of group q - lag;
-// the expanders of the last `lag` groups come after the last tile.  Placement is for speed only -- an
-// expander checks what it needs and waits (bounded) if it is early.
-enum { ROLE_NONE = 0, ROLE_SCAN = 1, ROLE_EXPAND = 2 };
+// Grid layout (TPG tiles per group).  An expander is a WAVE: what it mostly does is wait for loads, and every
+// wave slot it holds meanwhile is one the scan cannot fill (measured: four waves per group among the tiles
+// slow the scan by 19 %).  So among the scan tiles an expander workgroup takes a QUAD of four groups, one per
+// wave, placed behind the tiles of the quad `lag` groups further on; its integer work hides under the scan.
+// The last `lag` groups have no scan to hide under: their expander workgroups follow the last tile, one per
+// group, each wave a quarter of the group's steps.  Placement is for speed only -- an expander checks what it
+// needs and waits (bounded) if it is early.
+enum { ROLE_NONE = 0, ROLE_SCAN = 1, ROLE_EXPAND_QUAD = 2, ROLE_EXPAND_GROUP = 3 };
 struct Role { uint32_t kind; uint32_t index; };
 
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-    return (uint64_t)uniform_u32((uint32_t)v) | ((uint64_t)uniform_u32((uint32_t)(v >> 32)) << 32);
+
+// Groups expanded by the trailing workgroups: at least the requested lag, and such that what is left in front is
+// whole quads.
+__host__ __device__ inline uint32_t trailing_groups(uint32_t groups, uint32_t lag_req) {
+    const uint32_t quads = groups > lag_req ? (groups - lag_req) / 4u : 0u;
+    return groups - 4u * quads;
 }
 
 // All in 32 bits (the host keeps a launch under 2^31 workgroups) and pinned to SGPRs: the role and everything
 // derived from it is wave-uniform, and a 64-bit division would be done -- and then kept -- in vector registers.
 template <int TPG>
 __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
-    constexpr uint32_t period = TPG + 1;
+    constexpr uint32_t quad_tiles = 4u * TPG, period = quad_tiles + 1u;
     const uint32_t b = blockIdx.x + (uint32_t)a.block_base;
-    const uint32_t main_blocks = groups * period;
-    const uint32_t lag = a.lag < groups ? a.lag : groups;
+    const uint32_t tile_quads = (groups + 3u) / 4u;
+    const uint32_t main_blocks = tile_quads * period;
+    const uint32_t lag = trailing_groups(groups, a.lag);               // groups with a trailing expander workgroup
+    const uint32_t quads = (groups - lag) / 4u, lag_quads = tile_quads - quads;
     Role r;
     r.kind = ROLE_NONE;
     r.index = 0;
     if (b < main_blocks) {
         const uint32_t q = b / period, rr = b % period;
-        if (rr < TPG) { r.kind = ROLE_SCAN; r.index = q * TPG + rr; }
-        else if (q >= lag) { r.kind = ROLE_EXPAND; r.index = q - lag; }
+        if (rr < quad_tiles) { r.kind = ROLE_SCAN; r.index = q * quad_tiles + rr; }
+        else if (q >= lag_quads) { r.kind = ROLE_EXPAND_QUAD; r.index = q - lag_quads; }   // < quads by construction
     } else if (b - main_blocks < lag) {
-        r.kind = ROLE_EXPAND;
+        r.kind = ROLE_EXPAND_GROUP;
         r.index = groups - lag + (b - main_blocks);
     }
     r.kind = uniform_u32(r.kind);
@@ -560,58 +602,132 @@ __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
     return r;
 }
 
-// The hand-off words of a query are zeroed by the NEXT query of the context, which runs on the other half
-// of the ping-pong pair (plain stores: the kernel boundary publishes them).
-__device__ __forceinline__ void zero_other_half(const EvalArgs &a) {
-    if (a.block_base != 0) return;
-    const uint64_t n = a.zero_groups, ns = (n + kSuperGroups - 1) / kSuperGroups;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-        a.zgword[i] = 0ull;
-        a.zdeferred[i] = 0u;
-        if (i < ns) a.zsword[i] = 0ull;
+// The two counters of a query (ctl) are the only words that need zeroing: the query does it for the NEXT
+// one, which uses the other half of a ping-pong pair (plain stores: the kernel boundary publishes them).
+__device__ __forceinline__ void zero_other_ctl(const EvalArgs &a) {
+    if (a.block_base == 0 && blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
+}
+
+// The calling expander leader has finished group g.  True for exactly one caller of the launch: the last one.
+__device__ __forceinline__ bool last_expander(const EvalArgs &a, uint64_t g, uint64_t groups, uint32_t lane) {
+    uint32_t last = 0;
+    if (lane == 0) {
+        const uint32_t shard = (uint32_t)(g % kCtlShards);
+        const uint32_t in_shard = (uint32_t)(groups / kCtlShards) + (shard < groups % kCtlShards ? 1u : 0u);
+        if (__hip_atomic_fetch_add(a.ctl + shard * kCtlStride, 1u, PQPS_AGENT) + 1u == in_shard) {
+            const uint32_t shards = groups < (uint64_t)kCtlShards ? (uint32_t)groups : (uint32_t)kCtlShards;
+            last = __hip_atomic_fetch_add(a.ctl + kCtlTop, 1u, PQPS_AGENT) + 1u == shards ? 1u : 0u;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < kCtlWords) a.zctl[threadIdx.x] = 0u;
+    return uniform_u32(last) != 0;
 }
 
 // End of a scan tile of TS steps.  Every wave has left the counts of its steps in sh.tile_cnt, drained its
-// match-word stores and passed the workgroup's barrier; wave 0 publishes: the non-zero counts (the array is
-// all zero between queries), then ONE atomic add of (steps, matches) to the tile's group word.
+// match-word stores and passed the workgroup's barrier; wave 0 publishes the count words with the query's
+// epoch: an expander that finds all count words of its group tagged with it knows the group's match words are
+// in memory.  One store instruction, no atomic, nothing to wait for.
 template <int TS>
 __device__ __forceinline__ void publish_tile(const EvalArgs &a, const FusedShared &sh, const Extent &ex, uint64_t tile, uint32_t lane) {
     const uint64_t first = tile * TS;
     const uint32_t steps_in_tile = ex.steps - first < (uint64_t)TS ? (uint32_t)(ex.steps - first) : (uint32_t)TS;
-    const uint32_t c = lane < steps_in_tile ? sh.tile_cnt[lane] : 0u;
-    const uint32_t total = wave_sum_u32(c & 0x0FFFFFFFu);
-    bool stored = false;
     if (tile == 0 && a.accumulate) {                            // gather: results are appended behind *out_count
         if (lane == 0) st_sc1(a.base_slot, *a.out_count);
-        stored = true;
+        drain_stores();                                         // in memory before anything an expander waits for
     }
-    if (total) {
-        if (c & 0x0FFFFFFFu) st_sc1(a.counts + first + lane, c);
-        stored = true;
-    }
-    if (stored) drain_stores();
-    if (lane == 0)
-        __hip_atomic_fetch_add(a.gword + first / kGroupSteps, ((uint64_t)steps_in_tile << kArrShift) | (uint64_t)total, PQPS_AGENT);
+    if (lane < steps_in_tile) st_sc1(a.counts + first + lane, sh.tile_cnt[lane] | (a.epoch << kEpochShift));
 }
 
-// One wave's share of a scan tile: count word into LDS, match words (if any) to memory and drained.
+// Sum duty of a scan tile.  The expander of a group needs the sums of the groups in front of it; a sum that only
+// the group's own expander published would reach its neighbours a poll round too late (they start within
+// nanoseconds of each other), and every round an expander waits is a wave slot the scan cannot use.  So the
+// FIRST tile of group q also sums up group q - sum_lag, whose count words have long been written: one extra
+// 256-byte load issued next to the tile's column loads, consumed after the tile's own work.  Pure hint: if
+// those count words are not all there yet, the group's expander publishes the sum itself.
+// The SECOND tile of a group does the same one level up, for the supergroup that ended sum_lag groups ago -- from
+// its 4096 count words (16 KB read by one wave, once per 1024 tiles), not from its 64 group sums, so that the two
+// duties do not wait for each other.
+struct SumDuty { uint32_t c; uint32_t on; uint64_t g; };           // on: 1 = group sum, 2 = supergroup sum
+
+template <int TPG>
+__device__ __forceinline__ SumDuty sum_duty_load(const EvalArgs &a, uint32_t tile, uint32_t wv, uint32_t lane) {
+    SumDuty d;
+    d.c = 0; d.on = 0; d.g = 0;
+    if (wv != 0) return d;                                          // uniform
+    const uint32_t q = tile / TPG, t_in = tile % TPG;
+    if (t_in == 0 && q >= a.sum_lag) {
+        d.g = q - a.sum_lag;
+        d.on = 1;
+        d.c = ld_sc1(a.counts + d.g * kGroupSteps + lane);
+    } else if (t_in == 1 && q >= a.sum_lag && (q - a.sum_lag) % kSuperGroups == kSuperGroups - 1) {
+        d.g = (q - a.sum_lag) / kSuperGroups;                       // the supergroup whose last group is q - sum_lag
+        d.on = 2;
+    }
+    return d;
+}
+
+__device__ __forceinline__ void sum_duty_finish(const EvalArgs &a, const SumDuty &d, uint32_t lane) {
+    const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
+    if (d.on == 1) {
+        if (__all((d.c >> kEpochShift) == a.epoch)) {
+            const uint32_t sum = wave_sum_u32(d.c & kCountMask);
+            if (lane == 0) st_sc1(a.gsum + d.g, tag | (uint64_t)sum);
+        }
+    } else if (d.on == 2) {
+        const uint64_t *pairs = (const uint64_t *)(a.counts + d.g * kSuperGroups * kGroupSteps);     // 2048 pairs of count words
+        const uint64_t both = ((uint64_t)a.epoch << 48) | ((uint64_t)a.epoch << kEpochShift);
+        bool ok = true;
+        uint32_t sum = 0;
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {                               // 8 loads in flight at a time
+            uint64_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = ld_sc1(pairs + (r * 8 + i) * 64 + lane);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                ok = ok && (w[i] & 0xFFFF0000FFFF0000ull) == both;
+                sum += (uint32_t)(w[i] & kCountMask) + (uint32_t)((w[i] >> 32) & kCountMask);
+            }
+        }
+        if (__all(ok)) {
+            const uint64_t total = wave_sum_u64((uint64_t)sum);
+            if (lane == 0) st_sc1(a.ssum + d.g, tag | total);
+        }
+    }
+}
+
+// One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
     if (cnt) store_mask(a, step, mbits, lane);
-    if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << 28);
+    if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << kRplShift);
 }
 
 // ---- expand: match words -> ascending row IDs ------------------------------------------------------------
 // One step: the scan left 16 match bits per lane in its load layout (bit p of lane l <-> row
 // (p / RPL) * 64 * RPL + l * RPL + p % RPL).  First bring them into ROW order -- lane d gets the bits of rows
 // 16d .. 16d+15, which sit in 16/RPL source lanes.  Then
-//   few matches:  one wave scan of the per-lane popcounts gives every lane its first output slot; a lane writes
-//                 the IDs of its set bits one after the other (neighbouring lanes write neighbouring slots);
+//   few matches:  one wave scan of the per-lane popcounts gives every lane its rank; the IDs go to a ring in
+//                 LDS and leave it 64 at a time, one full store instruction per 256 bytes of output -- among
+//                 the scan tiles a CU's memory pipeline is full of their loads, and what an expander pays for
+//                 is every instruction it puts into that queue, not the bytes;
 //   many matches: 64 rows at a time -- their match bits are the words of 4 lanes, read into an SGPR pair with
 //                 v_readlane; rank inside the 64 = mbcnt, so the 64 lanes store to consecutive slots.
-// Neither form touches LDS.
+// The IDs of consecutive steps are consecutive in the output, so the ring carries over from step to step.
+struct OutRing {
+    uint32_t head, pending;          // wave-uniform: ring position of the oldest staged ID, staged IDs
+    uint64_t pos;                    // output slot of the oldest staged ID (= of the next ID when nothing is staged)
+};
+
+__device__ __forceinline__ void ring_flush(const EvalArgs &a, uint32_t *ring, OutRing &r, uint32_t lane, uint32_t n) {
+    // n <= 64 staged IDs leave in one store instruction
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the same wave wrote the ring
+    const uint32_t v = ring[(r.head + lane) & (kStageRing - 1)];
+    if (lane < n && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = v;
+    r.head = (r.head + n) & (kStageRing - 1);
+    r.pending -= n;
+    r.pos += n;
+}
+
 template <int RL>                                               // log2(RPL): 2, 3 or 4
 __device__ __forceinline__ uint32_t row_order_word(uint32_t m16, uint32_t lane) {
     constexpr uint32_t RPL = 1u << RL, S = 16u / RPL;              // S source lanes per destination lane
@@ -630,31 +746,34 @@ __device__ __forceinline__ uint32_t row_order_word(uint32_t m16, uint32_t lane) 
     }
 }
 
+template <bool GATHER>
 __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t m16, uint32_t rpl_log2,
-                                            uint32_t count, uint64_t out_off, uint32_t lane) {
+                                            uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
     uint32_t word;
     switch (rpl_log2) {                                             // uniform
     case 2: word = row_order_word<2>(m16, lane); break;
     case 3: word = row_order_word<3>(m16, lane); break;
     default: word = m16; break;
     }
-    const bool gather = a.cand != nullptr;                          // uniform
     const uint32_t step_row0 = (uint32_t)(step * kStepRows);
     if (count <= kDirectIds) {
         const uint32_t cnt = __popc(word);
         const uint32_t incl = wave_incl_scan_u32(cnt);
-        uint64_t pos = out_off + (incl - cnt);
+        uint32_t slot = r.head + r.pending + (incl - cnt);
         const uint32_t r0 = step_row0 + lane * 16u;
         while (word) {                                              // set bits only, ascending rows
             const uint32_t j = (uint32_t)__builtin_ctz(word);
             word &= word - 1;
             // gather: the candidate number of the row (a set bit implies the row lies inside the probed range)
-            const uint32_t id = gather ? a.cand[begin + r0 + j] : r0 + j;
-            if (pos < a.out_cap) a.out_ids[pos] = id + a.id_base;
-            pos++;
+            uint32_t id = r0 + j;
+            if constexpr (GATHER) id = a.cand[begin + r0 + j];
+            ring[slot & (kStageRing - 1)] = id + a.id_base;
+            slot++;
         }
+        r.pending += count;
+        while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
     } else {
-        uint64_t base = out_off;
+        if (r.pending) ring_flush(a, ring, r, lane, r.pending);     // < 64 staged IDs from the steps before
 #pragma unroll 1
         for (uint32_t s = 0; s < 16; s++) {
             // the match bits of rows 64s .. 64s+63 are the words of lanes 4s .. 4s+3: wave-uniform lane numbers, so
@@ -666,190 +785,337 @@ __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, u
             const uint64_t b = (uint64_t)(w0 | (w1 << 16)) | ((uint64_t)(w2 | (w3 << 16)) << 32);
             if (b) {                                                // uniform
                 if ((b >> lane) & 1ull) {
-                    const uint64_t o = base + mbcnt(b);
+                    const uint64_t o = r.pos + mbcnt(b);
                     const uint32_t row = step_row0 + 64u * s + lane;
-                    const uint32_t id = gather ? a.cand[begin + row] : row;
+                    uint32_t id = row;
+                    if constexpr (GATHER) id = a.cand[begin + row];
                     if (o < a.out_cap) a.out_ids[o] = id + a.id_base;
                 }
-                base += (uint64_t)__popcll(b);
+                r.pos += (uint64_t)__popcll(b);
             }
         }
     }
 }
 
-// Steps of group g that exist (the last group can be short).
-__device__ __forceinline__ uint32_t group_steps(const Extent &ex, uint64_t g) {
-    const uint64_t left = ex.steps - g * kGroupSteps;
-    return left < (uint64_t)kGroupSteps ? (uint32_t)left : (uint32_t)kGroupSteps;
-}
+__device__ __forceinline__ bool word_valid(const EvalArgs &a, uint64_t w) { return (uint32_t)(w >> kWordEpochShift) == a.epoch; }
 
-// Polls (one wave, all lanes the same word) until every step of group g has arrived.
-__device__ __forceinline__ bool wait_group(const EvalArgs &a, uint64_t g, uint32_t need, uint32_t limit, uint64_t &sum) {
-    for (uint32_t spins = 0;; spins++) {
-        const uint64_t w = ld_sc1(a.gword + g);
-        if ((uint32_t)(w >> kArrShift) == need) { sum = w & kSumMask; return true; }
-        if (spins >= limit) return false;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
-// Polls until everything in front of group g has arrived -- the supergroups before its own (every group
-// forwarded) and the groups before it in its own supergroup -- and sums their matches.
-__device__ __forceinline__ bool wait_prefix(const EvalArgs &a, uint64_t g, uint32_t limit, uint32_t lane, uint64_t &psum) {
-    const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
-    for (uint32_t spins = 0;; spins++) {
-        bool ok = true;
-        uint64_t acc = 0;
-        for (uint64_t j = lane; j < sg; j += 64) {
-            const uint64_t w = ld_sc1(a.sword + j);
-            ok = ok && (uint32_t)(w >> kArrShift) == (uint32_t)kSuperGroups;
-            acc += w & kSumMask;
-        }
-        if (lane < g_in) {
-            const uint64_t w = ld_sc1(a.gword + sg * kSuperGroups + lane);
-            ok = ok && (uint32_t)(w >> kArrShift) == (uint32_t)kGroupSteps;
-            acc += w & kSumMask;
-        }
-        if (__all(ok)) { psum = wave_sum_u64(acc); return true; }
-        if (spins >= limit) return false;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
-// Wave 0, once group g and everything in front of it has arrived: the group's step counts go to LDS for the
-// four waves, and back to zero in memory for the next query.
-__device__ __forceinline__ void fetch_group_counts(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane) {
+// One look at what the expander of group g waits for, everything asked for in one round of loads.
+//   its own group     every count word of the group carries the epoch (=> the group's match words are in
+//                     memory); lane l keeps step l's word in `cw`;
+//   what is in front  the ssum of the supergroups before its own -- for the NEAR ones just before it, whose words
+//                     may not be out yet (always so at the end of the table, where no tile does sum duty), the 64
+//                     gsums serve as well -- and the gsum of the earlier groups of its own supergroup.
+// `left`: bit 0 = own group still incomplete, bit 1 = front still unknown; a part that is settled is not read
+// again.  Returns the bits that are still open.
+template <int NEAR>
+__device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
+                                               uint32_t &cw, uint64_t &psum, uint64_t &own_super) {
+    uint32_t now = 0;
     const uint64_t step = g * kGroupSteps + lane;
-    uint32_t c = 0;
-    if (step < ex.steps) {
-        c = ld_sc1(a.counts + step);
-        if (c) st_sc1(a.counts + step, 0u);
+    uint32_t c = a.epoch << kEpochShift;
+    if ((left & 1u) && step < ex.steps) c = ld_sc1(a.counts + step);
+    if (left & 2u) {                                                // uniform
+        const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
+        const uint64_t far = sg > (uint64_t)NEAR ? sg - NEAR : 0;   // supergroups [0, far): by their words only
+        bool ok = true;
+        uint64_t acc = 0, mine = 0;
+        for (uint64_t j = lane; j < far; j += 64) {
+            const uint64_t w = ld_sc1(a.ssum + j);
+            ok = ok && word_valid(a, w);
+            acc += w & kWordMask;
+        }
+        uint64_t ps = 0, pg[NEAR > 0 ? NEAR : 1];                   // supergroups [far, sg): word (lane k) or groups
+        if (far + lane < sg) ps = ld_sc1(a.ssum + far + lane);
+#pragma unroll
+        for (int k = 0; k < NEAR; k++) {
+            pg[k] = 0;
+            if (far + k < sg) pg[k] = ld_sc1(a.gsum + (far + k) * kSuperGroups + lane);
+        }
+        if (lane < g_in) {                                          // earlier groups of the own supergroup
+            const uint64_t w = ld_sc1(a.gsum + sg * kSuperGroups + lane);
+            ok = ok && word_valid(a, w);
+            mine = w & kWordMask;
+        }
+        bool all_ok = __all(ok);
+        const uint64_t ps_ok = __ballot(far + lane < sg && word_valid(a, ps));
+        if (far + lane < sg && word_valid(a, ps)) acc += ps & kWordMask;
+#pragma unroll
+        for (int k = 0; k < NEAR; k++) {
+            if (far + k < sg && !((ps_ok >> k) & 1ull)) {           // uniform
+                if (__all(word_valid(a, pg[k]))) acc += pg[k] & kWordMask;
+                else all_ok = false;
+            }
+        }
+        if (all_ok) {
+            own_super = wave_sum_u64(mine);
+            psum = wave_sum_u64(acc) + own_super;
+        } else {
+            now |= 2u;
+        }
     }
-    sh.counts[lane] = c;
+    if (left & 1u) {
+        if (__all((c >> kEpochShift) == a.epoch)) cw = c; else now |= 1u;
+    }
+    return now;
 }
 
-// All four waves: wave w turns the match words of steps 16w .. 16w+15 of group g into row IDs.
-__device__ __forceinline__ void expand_group(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t wave) {
-    const uint32_t cw = sh.counts[lane];
-    const uint64_t group_off = sh.group_off;
-    const uint32_t my_cnt = cw & 0x0FFFFFFFu;
+// FOUR consecutive steps at once (4096 rows, at most kDirectIds matches between them): lane L takes rows
+// [64 L, 64 L + 64) of the block -- step L / 16, rows 64 (L % 16) .. of it -- and pulls their 64 match bits out
+// of the parked match words of that step: with RPL rows per lane and chunk they are the same RPL-bit field of
+// 64 / RPL neighbouring lanes' words, i.e. 8, 16 or 32 contiguous bytes of LDS.  One wave scan ranks all IDs of
+// the block.  (Per step the same work costs four times the instructions, and every one of them waits its turn
+// among the scan tiles' waves.)
+template <bool GATHER>
+__device__ __forceinline__ void expand_block(const EvalArgs &a, uint64_t begin, uint64_t step0, uint32_t rpl_log2, uint32_t total, uint32_t nb,
+                                             const uint16_t (*park)[64], uint32_t lane, uint32_t *ring, OutRing &r) {
+    const uint32_t s = lane >> 4, q = lane & 15u;
+    const uint16_t *row = park[s];
+    uint64_t w;
+    if (rpl_log2 == 4) {                                            // uniform: 16 rows per lane -> 4 lanes' words, in order
+        w = *(const uint64_t *)(row + 4u * q);
+    } else if (rpl_log2 == 3) {                                     // 8 rows per lane and chunk: byte q / 8 of 8 lanes' words
+        const uint4 d = *(const uint4 *)(row + 8u * (q & 7u));
+        const uint32_t sh8 = 8u * (q >> 3);
+        const uint32_t x[4] = {d.x, d.y, d.z, d.w};
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t two = ((x[i] >> sh8) & 0xFFu) | (((x[i] >> (16u + sh8)) & 0xFFu) << 8);     // lanes 2i, 2i+1
+            if (i < 2) lo |= two << (16 * i); else hi |= two << (16 * (i - 2));
+        }
+        w = (uint64_t)lo | ((uint64_t)hi << 32);
+    } else {                                                        // 4 rows per lane and chunk: nibble q / 4 of 16 lanes' words
+        const uint4 d0 = *(const uint4 *)(row + 16u * (q & 3u)), d1 = *(const uint4 *)(row + 16u * (q & 3u) + 8);
+        const uint32_t sh4 = 4u * (q >> 2);
+        const uint32_t x[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t two = ((x[i] >> sh4) & 0xFu) | (((x[i] >> (16u + sh4)) & 0xFu) << 4);        // lanes 2i, 2i+1
+            if (i < 4) lo |= two << (8 * i); else hi |= two << (8 * (i - 4));
+        }
+        w = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    if (!((nb >> s) & 1u)) w = 0;                                   // an empty step: its slot was not filled
+    const uint32_t cnt = (uint32_t)__popcll(w);
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    uint32_t slot = r.head + r.pending + (incl - cnt);
+    const uint32_t r0 = (uint32_t)(step0 * kStepRows) + lane * 64u;
+    while (w) {                                                     // set bits only, ascending rows
+        const uint32_t j = (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        uint32_t id = r0 + j;
+        if constexpr (GATHER) id = a.cand[begin + r0 + j];
+        ring[slot & (kStageRing - 1)] = id + a.id_base;
+        slot++;
+    }
+    r.pending += total;
+    while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
+}
+
+// The calling wave turns the match words of steps [c0, c1) of group g (both multiples of 16) into row IDs
+// (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
+template <bool GATHER>
+__device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
+                                             uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off) {
+    const uint32_t my_cnt = cw & kCountMask;
     const uint32_t incl = wave_incl_scan_u32(my_cnt);
     const uint64_t my_off = group_off + (incl - my_cnt);
-    if (g + 1 == ex.groups && wave == 0 && lane == 63) *a.out_count = group_off + incl;
-    const uint64_t nonempty = __ballot(my_cnt != 0);
-    const uint32_t c0 = wave * (kGroupSteps / kWaves);
-    const uint32_t bits = uniform_u32((uint32_t)(nonempty >> c0) & 0xFFFFu);
-    if (!bits) return;                                              // uniform for the wave
-    // All match words of the wave's non-empty steps are requested at once (one memory latency) and parked in LDS:
-    // slot k takes the k-th non-empty step; slots past the last one re-read the first (no branch between the
-    // loads, and a line this wave has just asked for).
-    const uint16_t *gmask = a.masks + (g * kGroupSteps + c0) * 64 + lane;
-    const uint32_t first = (uint32_t)__builtin_ctz(bits);
-    uint32_t rest = bits;
-    uint32_t mreg[kGroupSteps / kWaves];
-#pragma unroll
-    for (uint32_t k = 0; k < kGroupSteps / kWaves; k++) {
-        const uint32_t i = rest ? (uint32_t)__builtin_ctz(rest) : first;                 // wave-uniform
-        rest &= rest - 1;
-        mreg[k] = ld_sc1(gmask + (size_t)i * 64);
+    if (g + 1 == ex.groups && c0 == 0 && lane == 63) *a.out_count = group_off + incl;
+    const uint64_t span = (c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
+    const uint64_t nonempty = __ballot(my_cnt != 0) & span;         // non-empty steps of the range (wave-uniform)
+    if (!nonempty) return;
+    // matches of the block of 4 steps a lane's step belongs to (DPP quad sums)
+    uint32_t quad = my_cnt + dpp_or_zero<0xb1>(my_cnt);
+    quad += dpp_or_zero<0x4e>(quad);
+    const uint32_t rpl_log2 = ((uint32_t)__builtin_amdgcn_readlane((int)cw, (int)__builtin_ctzll(nonempty)) >> kRplShift) & 7u;   // one per query
+    uint32_t *ring = sh.stage[park];
+    OutRing r;
+    r.head = 0;
+    r.pending = 0;
+    r.pos = readlane_u64(my_off, (int)__builtin_ctzll(nonempty));   // the range's IDs form one run of the output
+    for (uint32_t w0 = c0; w0 < c1; w0 += kGroupSteps / kWaves) {   // 16 steps at a time
+        const uint32_t bits = uniform_u32((uint32_t)(nonempty >> w0) & 0xFFFFu);
+        if (!bits) continue;
+        // The match words of the window's non-empty steps go from memory straight into LDS (LDS-DMA: 128 bytes per
+        // step by 32 lanes, no vector register in between), all requested before any is awaited: one memory
+        // latency per window.  The slot of an empty step keeps whatever it held: nobody looks at it.
+        {
+            typedef __attribute__((address_space(1))) const void global_cvoid;
+            typedef __attribute__((address_space(3))) void lds_void;
+            const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + w0) * 64) + lane;
+            for (uint32_t rest = bits; rest; rest &= rest - 1) {    // uniform
+                const uint32_t k = (uint32_t)__builtin_ctz(rest);
+                if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not count LDS-DMA as a write to LDS)
+        }
+        for (uint32_t bb = 0; bb < 4; bb++) {                       // blocks of 4 steps
+            const uint32_t nb = (bits >> (4 * bb)) & 0xFu;
+            if (!nb) continue;
+            const uint32_t sidx0 = w0 + 4 * bb;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
+            if (total <= kDirectIds) {
+                expand_block<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, rpl_log2, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
+            } else {
+                for (uint32_t i = 0; i < 4; i++) {
+                    if (!((nb >> i) & 1u)) continue;
+                    const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i));
+                    expand_step<GATHER>(a, ex.begin, g * kGroupSteps + sidx0 + i, sh.mask[park][4 * bb + i][lane], rpl_log2, cwi & kCountMask,
+                                        lane, ring, r);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the slice is filled again
     }
-#pragma unroll
-    for (uint32_t k = 0; k < kGroupSteps / kWaves; k++) sh.mask[wave][k][lane] = (uint16_t)mreg[k];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave wrote and reads
-    rest = bits;
-    for (uint32_t k = 0; rest; k++) {
-        const int sidx = (int)(c0 + (uint32_t)__builtin_ctz(rest));
-        rest &= rest - 1;
-        const uint64_t step_off = readlane_u64(my_off, sidx);       // sidx is wave-uniform: v_readlane, no LDS crossbar
-        const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, sidx);
-        expand_step(a, ex.begin, g * kGroupSteps + (uint64_t)sidx, sh.mask[wave][k][lane], cwi >> 28, cwi & 0x0FFFFFFFu,
-                    step_off, lane);
+    if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+}
+
+// The leader wave of group g settles what the group needs: waits (bounded) for its count words and for the sums
+// in front of it, publishes the group's own sum (and the supergroup's, if it is its last group) unless a tile
+// has done so, and takes its ticket.  Returns false if it gave the group up.
+//
+// Recovery: the ONE leader that is last to leave its wait looks after the groups others gave up on (which
+// in-order dispatch never produces).  By then every other expander is past its wait, so this wave is the
+// only one on the chip that waits for anything, and what it waits for are scan tiles, which wait for nothing.
+// It first publishes the sums that are missing, in ascending order, then expands the deferred groups.
+constexpr int kNearGroups = 6;     // supergroups in front whose group sums are read along with their words when a word is missing
+
+template <int NEAR>
+__device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
+                                             uint32_t &cw, uint64_t &psum) {
+    const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
+    uint64_t own_super = 0;
+    uint32_t left = 3u;
+    bool sum_out = recovery;                                        // (the recovery pass has published every sum beforehand)
+    // Far from the end of the table every word in front has been written by a tile's sum duty: the first look reads
+    // just those; only if one is missing (or near the end, where no tile does sum duty) the group sums behind the
+    // missing supergroup words are read as well.
+    bool light = g + a.sum_lag + (uint64_t)(NEAR + 1) * kSuperGroups < ex.groups;
+    for (uint32_t spins = 0;; spins++) {
+        left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super) : poll_group<NEAR>(a, ex, g, lane, left, cw, psum, own_super);
+        light = false;
+        if (!(left & 1u) && !sum_out) {
+            // the group's matches: normally a tile has summed them up long ago; at the end of the table nobody has
+            const uint32_t sum = wave_sum_u32(cw & kCountMask);
+            if (lane == 0) st_sc1(a.gsum + g, tag | (uint64_t)sum);
+            sum_out = true;
+        }
+        if (left == 0 || spins >= limit) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: payload loads stay behind the polls
+    const bool ok = left == 0;
+    if (ok) {
+        // likewise the supergroup's total, by the leader of its last group
+        const uint32_t sum = wave_sum_u32(cw & kCountMask);
+        if (lane == 0 && g % kSuperGroups == kSuperGroups - 1) st_sc1(a.ssum + g / kSuperGroups, tag | (own_super + (uint64_t)sum));
+    } else if (recovery) {
+        if (lane == 0) st_sc1(a.status, 1u);                        // something never arrived: reported, never silent
+    } else {
+        if (lane == 0) {
+            st_sc1(a.deferred + g, (a.epoch << kEpochShift) | (sum_out ? 3u : 1u));
+            __hip_atomic_fetch_add(a.ctl + kCtlDeferred, 1u, PQPS_AGENT);
+        }
+        drain_stores();                                             // ... in memory before this group counts as finished
+    }
+    return ok;
+}
+
+// Recovery pass: see settle_group.  One wave, cold code.
+template <bool GATHER>
+__device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint32_t lane_in, uint32_t park) {
+    uint32_t lane = lane_in;
+    asm volatile("" : "+v"(lane));                                  // (keeps this cold code's address arithmetic out of the callers' registers)
+    const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
+    bool alive = true;                                              // pass 1: the group sums nobody has published, in ascending order
+#pragma unroll 1
+    for (uint64_t p0 = 0; alive && p0 < ex.groups; p0 += 64) {
+        const uint32_t f = p0 + lane < ex.groups ? ld_sc1(a.deferred + p0 + lane) : 0u;
+        uint64_t fw = __ballot((f >> kEpochShift) == a.epoch && (f & 3u) == 1u);
+        while (alive && fw) {
+            const uint64_t gg = p0 + (uint64_t)__builtin_ctzll(fw);
+            fw &= fw - 1;
+            uint32_t cw = 0;
+            uint64_t unused = 0;
+            alive = false;
+#pragma unroll 1
+            for (uint32_t spins = 0; spins < kRecoverSpins; spins++) {
+                if (!(poll_group<0>(a, ex, gg, lane, 1u, cw, unused, unused) & 1u)) { alive = true; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            const uint32_t sum = wave_sum_u32(cw & kCountMask);
+            if (alive && lane == 0) st_sc1(a.gsum + gg, tag | (uint64_t)sum);
+        }
+    }
+    if (!alive && lane == 0) st_sc1(a.status, 1u);                  // a scan tile never arrived: reported, never silent
+    drain_stores();
+    // ... and the supergroup words still missing (every group sum is out now)
+#pragma unroll 1
+    for (uint64_t j = lane; alive && j * kSuperGroups + kSuperGroups <= ex.groups; j += 64) {
+        if (word_valid(a, ld_sc1(a.ssum + j))) continue;
+        uint64_t sum = 0;
+        bool all = true;
+#pragma unroll 1
+        for (uint32_t k = 0; k < kSuperGroups; k++) {
+            const uint64_t w = ld_sc1(a.gsum + j * kSuperGroups + k);
+            all = all && word_valid(a, w);
+            sum += w & kWordMask;
+        }
+        if (all) st_sc1(a.ssum + j, tag | sum);
+    }
+    drain_stores();
+#pragma unroll 1
+    for (uint64_t f0 = 0; f0 < ex.groups; f0 += 64) {               // pass 2: expand what was given up, in ascending order
+        const uint32_t f = f0 + lane < ex.groups ? ld_sc1(a.deferred + f0 + lane) : 0u;
+        uint64_t todo = __ballot((f >> kEpochShift) == a.epoch && (f & 1u) != 0u);
+        while (todo) {
+            const uint64_t g = f0 + (uint64_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            uint32_t cw = 0;
+            uint64_t psum = 0;
+            if (!settle_group<kNearGroups>(a, ex, g, lane, kRecoverSpins, true, cw, psum)) continue;
+            const uint64_t base = a.accumulate ? ld_sc1(a.base_slot) : 0ull;
+            const uint32_t cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
+            expand_range<GATHER>(a, sh, ex, g, lane, 0, kGroupSteps, park, cnts, base + psum);
+        }
     }
 }
 
-// The expander workgroup of group g.
-//
-// Recovery: the ONE expander workgroup that is last to leave its wait looks after the groups others gave up
-// on (which in-order dispatch never produces).  By then every other expander is past its wait, so this
-// workgroup is the only one on the chip that waits for anything, and what it waits for are scan tiles, which
-// wait for nothing.  It first forwards what was never forwarded, then runs the same body over the deferred
-// groups in ascending order.
-__device__ __forceinline__ void expander(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g) {
+// An expander workgroup.  Among the scan tiles: four independent waves, one group each.  Behind the last tile:
+// one group, its leader wave settles it and hands count words and output slot to the other three through LDS.
+template <bool GATHER>
+__device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShared &sh, const Extent &ex, const Role &role) {
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
-    uint32_t ticket = 0;
-    bool recovery = false;                                          // uniform for the workgroup
-    uint64_t g0 = 0, todo = 0;                                      // recovery: deferred groups of [g0, g0 + 64) still to do
-    for (;;) {
-        if (wave == 0) {
-            uint64_t sum = 0, psum = 0;
-            uint32_t flags = 1u;
-            bool ok = true;
-            if (!recovery) {
-                ok = wait_group(a, g, group_steps(ex, g), a.spin_limit, sum);
-                if (ok) {
-                    // forward the group's matches to its supergroup word as soon as they are known: later supergroups wait for it
-                    if (lane == 0) __hip_atomic_fetch_add(a.sword + g / kSuperGroups, (1ull << kArrShift) | sum, PQPS_AGENT);
-                    flags |= 2u;
-                }
-            }
-            if (ok) ok = wait_prefix(a, g, recovery ? kRecoverSpins : a.spin_limit, lane, psum);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: payload loads stay behind the polls
-            if (ok) {
-                const uint64_t base = a.accumulate ? ld_sc1(a.base_slot) : 0ull;
-                fetch_group_counts(a, sh, ex, g, lane);
-                if (lane == 0) sh.group_off = base + psum;
-            } else if (recovery) {
-                if (lane == 0) st_sc1(a.status, 1u);                // something never arrived: reported, never silent
-            } else {
-                if (lane == 0) {
-                    st_sc1(a.deferred + g, flags);
-                    __hip_atomic_fetch_add(a.ctl + 1, 1u, PQPS_AGENT);
-                }
-                drain_stores();                                     // ... before this workgroup counts as past its wait
-            }
-            if (lane == 0) {
-                if (!recovery) ticket = __hip_atomic_fetch_add(a.ctl + 0, 1u, PQPS_AGENT);   // used after the expansion: latency hidden
-                sh.state = ok ? 1u : 0u;
-            }
+    const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
+    const bool leader = !shared || wave == 0;
+    const uint64_t g = shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave;
+    const uint32_t c0 = shared ? wave * (kGroupSteps / kWaves) : 0u, c1 = shared ? c0 + kGroupSteps / kWaves : (uint32_t)kGroupSteps;
+    bool ok = false;
+    uint32_t cnts = 0;
+    uint64_t group_off = 0;
+    if (leader) {
+        uint32_t cw = 0;
+        uint64_t psum = 0;
+        ok = settle_group<kNearGroups>(a, ex, g, lane, a.spin_limit, false, cw, psum);
+        if (ok) {
+            cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
+            group_off = (a.accumulate ? ld_sc1(a.base_slot) : 0ull) + psum;
+        }
+    }
+    if (shared) {
+        if (leader) {
+            sh.counts[lane] = cnts;
+            if (lane == 0) { sh.group_off = group_off; sh.state = ok ? 1u : 0u; }
         }
         __syncthreads();
-        if (sh.state) expand_group(a, sh, ex, g, lane, wave);
-        if (!recovery) {
-            if (wave == 0 && lane == 0)
-                sh.recover = ((uint64_t)ticket + 1 == ex.groups && ld_sc1(a.ctl + 1) != 0u) ? 1u : 0u;
-            __syncthreads();
-            if (!sh.recover) return;
-            recovery = true;
-            if (wave == 0) {                                        // pass 1: forward what was never forwarded
-                bool alive = true;
-                for (uint64_t f0 = 0; alive && f0 < ex.groups; f0 += 64) {
-                    const uint32_t f = f0 + lane < ex.groups ? ld_sc1(a.deferred + f0 + lane) : 0u;
-                    uint64_t fw = __ballot((f & 3u) == 1u);         // deferred and not forwarded
-                    while (alive && fw) {
-                        const uint64_t gg = f0 + (uint64_t)__builtin_ctzll(fw);
-                        fw &= fw - 1;
-                        uint64_t sum = 0;
-                        alive = wait_group(a, gg, group_steps(ex, gg), kRecoverSpins, sum);
-                        if (alive && lane == 0) __hip_atomic_fetch_add(a.sword + gg / kSuperGroups, (1ull << kArrShift) | sum, PQPS_AGENT);
-                    }
-                }
-                if (!alive && lane == 0) st_sc1(a.status, 1u);
-            }
-            g0 = 0;
-            const uint32_t f = lane < ex.groups ? ld_sc1(a.deferred + lane) : 0u;
-            todo = __ballot((f & 1u) != 0u);
-        }
-        // next deferred group (every wave reads the same flags: nobody writes them any more)
-        while (todo == 0) {
-            g0 += 64;
-            if (g0 >= ex.groups) return;
-            const uint32_t f = g0 + lane < ex.groups ? ld_sc1(a.deferred + g0 + lane) : 0u;
-            todo = __ballot((f & 1u) != 0u);
-        }
-        g = g0 + (uint64_t)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        __syncthreads();                                            // everyone is done with the previous group's LDS
+        ok = sh.state != 0u;
+        cnts = sh.counts[lane];
+        group_off = sh.group_off;
     }
+    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off);
+    // the expander that is last to finish looks after the groups others gave up on (if any)
+    if (leader && last_expander(a, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
 }
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
@@ -859,18 +1125,22 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves;                              // steps per tile
         __shared__ FusedShared sh;
-        zero_other_half(a);
+        zero_other_ctl(a);
         const Extent ex = scan_extent<GATHER>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<GATHER>(a, sh, ex, role); return; }
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step = (uint64_t)role.index * TS + wv;
+        const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);
         uint32_t cnt = 0;
         if (step < ex.steps) {
             const uint64_t step_row0 = step * kStepRows;
             uint32_t mbits;
-            if (!GATHER && step_row0 + kStepRows <= ex.n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
-            else mbits = eval_step_guarded<GATHER>(a, step_row0, ex.n_rows, ex.begin, lane);
+            if (GATHER) mbits = eval_step_guarded<true>(a, step_row0, ex.n_rows, ex.begin, lane);
+            else {
+                mbits = eval_step_full<NT>(a, step_row0, lane);
+                if (step_row0 + kStepRows > ex.n_rows) mbits &= rows_below<kRplGeneric>(step_row0, ex.n_rows, lane);   // the partial last step
+            }
             cnt = wave_sum_u32(__popc(mbits));
             tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
         } else if (lane == 0) {
@@ -878,7 +1148,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic
         }
         if (cnt) drain_stores();
         __syncthreads();
-        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
     } else {
         static_assert(!GATHER, "gather mode produces ID lists");
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
@@ -889,8 +1159,8 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic
         for (uint64_t step = wave; step < steps_used; step += n_waves) {
             const uint64_t step_row0 = step * kStepRows;
             uint32_t mbits = 0;
-            if (step_row0 + kStepRows <= n_rows) mbits = eval_step_full<NT>(a, step_row0, lane);
-            else mbits = eval_step_guarded<false>(a, step_row0, n_rows, 0, lane);
+            mbits = eval_step_full<NT>(a, step_row0, lane);
+            if (step_row0 + kStepRows > n_rows) mbits &= rows_below<kRplGeneric>(step_row0, n_rows, lane);             // the partial last step
             emit_step<MODE>(a, step, mbits, 2, n_rows, lane, wave_total);
         }
         finish_totals<MODE>(a, wave_total);
@@ -1106,7 +1376,7 @@ struct RawStep {
 
 // General tree of <= 6 leaves (row-mask path).
 template <int MODE, int W0, int W1, int W2, bool NT>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_spec_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 : 8) : 1) void eval_spec_kernel(const EvalArgs a) {
     // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
@@ -1119,41 +1389,40 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_spec_ke
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves;
         __shared__ FusedShared sh;
-        zero_other_half(a);
+        zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(a, sh, ex, role); return; }
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step = (uint64_t)role.index * TS + wv;
+        SumDuty duty;
         uint32_t cnt = 0;
-        if (step < full_steps) {
+        if (step < ex.steps) {
             RawStep<W0, W1, W2, RPL, U> A;
             A.template load<NT>(a, step * kStepRows + lane_off);
-            const uint32_t mbits = A.eval(a);
+            duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);       // behind the column loads, consumed after the tile's work
+            uint32_t mbits = A.eval(a);
+            if (step >= full_steps) mbits &= rows_below<RPL>(step * kStepRows, n_rows, lane);   // the partial last step
             cnt = wave_sum_u32(__popc(mbits));
             tile_step_out(a, sh, wv, step, cnt, mbits, log2i(RPL), lane);
-        } else if (step < ex.steps) {                           // the partial last step: guarded evaluator, RPL = 4 layout
-            const uint32_t mbits = eval_step_guarded<false>(a, step * kStepRows, n_rows, 0, lane);
-            cnt = wave_sum_u32(__popc(mbits));
-            tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
-        } else if (lane == 0) {
-            sh.tile_cnt[wv] = 0;
+        } else {
+            duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);
+            if (lane == 0) sh.tile_cnt[wv] = 0;
         }
         if (cnt) drain_stores();
         __syncthreads();
-        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
         uint64_t wave_total = 0;
-        for (uint64_t step = wave; step < full_steps; step += n_waves) {
+        const uint64_t steps = (n_rows + kStepRows - 1) / kStepRows;
+        for (uint64_t step = wave; step < steps; step += n_waves) {
             RawStep<W0, W1, W2, RPL, U> A;
             A.template load<NT>(a, step * kStepRows + lane_off);
-            emit_step<MODE>(a, step, A.eval(a), log2i(RPL), n_rows, lane, wave_total);
-        }
-        if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
-            const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
-            emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
+            uint32_t mbits = A.eval(a);
+            if (step >= full_steps) mbits &= rows_below<RPL>(step * kStepRows, n_rows, lane);   // the partial last step
+            emit_step<MODE>(a, step, mbits, log2i(RPL), n_rows, lane, wave_total);
         }
         finish_totals<MODE>(a, wave_total);
     }
@@ -1181,27 +1450,28 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves * S;                          // a tile = S adjacent steps per wave
         __shared__ FusedShared sh;
-        zero_other_half(a);
+        zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind == ROLE_EXPAND) { expander(a, sh, ex, role.index); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(a, sh, ex, role); return; }
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step0 = (uint64_t)role.index * TS + (uint64_t)wv * S;
 #pragma unroll
         for (int i = 0; i < S; i++)
-            if (step0 + i < full_steps) A[i].template load<NT>(a, (step0 + i) * kStepRows + lane_off);      // uniform guard
+            if (step0 + i < ex.steps) A[i].template load<NT>(a, (step0 + i) * kStepRows + lane_off);        // uniform guard
+        const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);   // behind the column loads, consumed after the tile's work
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const uint64_t step = step0 + (uint64_t)i;
             uint32_t cnt = 0, mbits = 0, lane_total = 0;
-            if (step < full_steps) {
+            if (step < ex.steps) {
                 A[i].template eval_chain_step<MODE, VC>(a, cnt, mbits, lane_total);
+                if (step >= full_steps) {                       // the partial last step
+                    mbits &= rows_below<RPL>(step * kStepRows, n_rows, lane);
+                    cnt = wave_sum_u32(__popc(mbits));
+                }
                 tile_step_out(a, sh, wv * S + i, step, cnt, mbits, log2i(RPL), lane);
-            } else if (step < ex.steps) {
-                mbits = eval_step_guarded<false>(a, step * kStepRows, n_rows, 0, lane);
-                cnt = wave_sum_u32(__popc(mbits));
-                tile_step_out(a, sh, wv * S + i, step, cnt, mbits, 2, lane);
             } else if (lane == 0) {
                 sh.tile_cnt[wv * S + i] = 0;
             }
@@ -1209,7 +1479,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
         }
         if (any) drain_stores();
         __syncthreads();
-        if (wv == 0) publish_tile<TS>(a, sh, ex, role.index, lane);
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -1231,9 +1501,11 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
                 wave_total += cnt;
             }
         }
-        if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {
-            const uint32_t mbits = eval_step_guarded<false>(a, full_steps * kStepRows, n_rows, 0, lane);
-            emit_step<MODE>(a, full_steps, mbits, 2, n_rows, lane, wave_total);
+        if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {      // the partial last step: match bits, trimmed
+            uint32_t cnt = 0, mbits = 0, unused = 0;
+            A[0].template load<NT>(a, full_steps * kStepRows + lane_off);
+            A[0].template eval_chain_step<MODE_IDS, VC>(a, cnt, mbits, unused);
+            wave_total += wave_sum_u32(__popc(mbits & rows_below<RPL>(full_steps * kStepRows, n_rows, lane)));
         }
         wave_total += wave_sum_u32(lane_total);
         finish_totals<MODE>(a, wave_total);

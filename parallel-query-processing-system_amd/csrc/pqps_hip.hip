@@ -293,13 +293,14 @@ struct pqps_ctx {
     uint64_t scratch_steps;     // capacity in steps of 1024 rows
     uint16_t *masks;            // [steps][64] match words
     uint32_t *counts;           // [steps] step counts; all zero between queries
-    // hand-off words of the ID-output launch: two halves used alternately; a query zeroes the half the
-    // previous one used.  Per half: ctl[kCtlWords] u32 | sword[supers] u64 | gword[groups] u64 | deferred[groups] u32
-    char *hand;
-    size_t hand_half_bytes;
-    uint64_t hand_groups, hand_supers;   // capacities
-    int parity;                 // half the next ID query uses
-    uint64_t dirty_groups[2];   // groups the last query on each half can have written
+    // hand-off words of the ID-output launch (filter_kernels.hpp): tagged with the query's epoch, so nothing but
+    // the two counters of ctl needs zeroing -- and those are a ping-pong pair, zeroed by the query before
+    uint64_t *gsum, *ssum;      // [hand_groups], [hand_groups / 64 + 1]
+    uint32_t *deferred;         // [hand_groups]
+    uint32_t *ctl;              // [2][kCtlWords]
+    uint64_t hand_groups;       // capacity
+    uint32_t epoch;             // of the last ID query; 1 .. 65535, then the tagged arrays are zeroed and it starts over
+    int parity;                 // ctl half the next ID query uses
     uint64_t *base_slot;        // gather: first output slot of the running query
     uint64_t *partials;         // workgroup totals of the scan (COUNT / FLAGS modes)
     uint32_t *status_host;      // mapped host word: set by a kernel whose recovery pass gave up
@@ -318,53 +319,45 @@ namespace {
 hipStream_t pick_stream(pqps_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
 void free_scratch(pqps_ctx *ctx) {
-    if (ctx->masks) (void)hipFree(ctx->masks);
-    if (ctx->counts) (void)hipFree(ctx->counts);
-    if (ctx->hand) (void)hipFree(ctx->hand);
-    if (ctx->base_slot) (void)hipFree(ctx->base_slot);
-    if (ctx->partials) (void)hipFree(ctx->partials);
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->hand = nullptr;
-    ctx->base_slot = nullptr; ctx->partials = nullptr;
+    void *all[] = {ctx->masks, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials};
+    for (void *p : all) if (p) (void)hipFree(p);
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->scratch_steps = 0;
 }
 
-size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// Epoch 0 = "never written": what every tagged word holds after this.
+int zero_tagged_words(pqps_ctx *ctx, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(ctx->counts, 0, ctx->scratch_steps * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(ctx->gsum, 0, ctx->hand_groups * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(ctx->ssum, 0, (ctx->hand_groups / kSuperGroups + 1) * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(ctx->deferred, 0, ctx->hand_groups * sizeof(uint32_t), s));
+    return PQPS_OK;
+}
 
 int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     if (ctx->scratch_steps >= steps && ctx->masks) return PQPS_OK;
     if (ctx->masks) { HIP_TRY(hipDeviceSynchronize()); free_scratch(ctx); }
     const uint64_t cap = steps + steps / 4 + 64;
     const uint64_t groups = (cap + kGroupSteps - 1) / kGroupSteps;
-    const uint64_t supers = (groups + kSuperGroups - 1) / kSuperGroups;
     HIP_TRY(hipMalloc((void **)&ctx->masks, cap * 64 * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
-    ctx->hand_groups = groups;
-    ctx->hand_supers = supers;
-    ctx->hand_half_bytes = align256(kCtlWords * 4) + align256(supers * 8) + align256(groups * 8) + align256(groups * 4);
-    HIP_TRY(hipMalloc((void **)&ctx->hand, 2 * ctx->hand_half_bytes));
+    HIP_TRY(hipMalloc((void **)&ctx->gsum, groups * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->ssum, (groups / kSuperGroups + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->deferred, groups * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->ctl, 2 * kCtlWords * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->base_slot, 64));
     HIP_TRY(hipMalloc((void **)&ctx->partials, kPartialSlots * sizeof(uint64_t)));
-    // the scan relies on: step counts all zero, both halves of the hand-off words zero
-    HIP_TRY(hipMemset(ctx->counts, 0, cap * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(ctx->hand, 0, 2 * ctx->hand_half_bytes));
-    HIP_TRY(hipMemset(ctx->partials, 0, kPartialSlots * sizeof(uint64_t)));
-    ctx->parity = 0;
-    ctx->dirty_groups[0] = ctx->dirty_groups[1] = 0;
     ctx->scratch_steps = cap;
+    ctx->hand_groups = groups;
+    int rc = zero_tagged_words(ctx, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(ctx->ctl, 0, 2 * kCtlWords * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ctx->partials, 0, kPartialSlots * sizeof(uint64_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    ctx->parity = 0;
+    ctx->epoch = 0;
     return PQPS_OK;
-}
-
-// Pointers into one half of the hand-off block.
-struct HandHalf { uint32_t *ctl; uint64_t *sword; uint64_t *gword; uint32_t *deferred; };
-
-HandHalf hand_half(const pqps_ctx *ctx, int half) {
-    char *p = ctx->hand + (size_t)half * ctx->hand_half_bytes;
-    HandHalf h;
-    h.ctl = (uint32_t *)p;                 p += align256(kCtlWords * 4);
-    h.sword = (uint64_t *)p;               p += align256(ctx->hand_supers * 8);
-    h.gword = (uint64_t *)p;               p += align256(ctx->hand_groups * 8);
-    h.deferred = (uint32_t *)p;
-    return h;
 }
 
 int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
@@ -534,13 +527,32 @@ uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps, bool streaming, uint32_t steps
     return (uint32_t)(g ? g : 1);
 }
 
-// Placement of the expander workgroups: `lag` groups behind the scan tiles of their group -- a little more than
-// the groups the chip has in flight (8 workgroups per CU), so that an expander normally finds everything it
-// needs already there.  (Speed only: an expander checks and waits.)
-uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
+// Placement in the grid.  The chip has ~8 workgroups per CU in flight, i.e. `base` groups, and a round of loads
+// takes about as long as `base` groups take to pass.  A group (and, from the same count words, a supergroup) is
+// summed up by a tile `base` groups behind it -- its count words are in memory by then -- and expanded by a wave
+// 2 * base groups behind it -- the sums in front of it are in memory by then.  Speed only: everybody checks what it
+// finds, and the expander waits if it must.
+uint32_t expand_lag_base(const pqps_ctx *ctx, uint32_t tiles_per_group) {
+    return (uint32_t)ctx->compute_units * 10u / (tiles_per_group + 1u);
+}
+
+uint32_t expand_sum_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
+    static const char *env = getenv("PQPS_SUM_LAG");                // huge: no tile sums anything up (tests: every expander does it itself)
+    if (env) return (uint32_t)strtoul(env, nullptr, 10);
+    return expand_lag_base(ctx, tiles_per_group);
+}
+
+// Expanders among the scan tiles hide their work under the scan, but hold wave slots the scan could use and leave
+// a pipeline of ~2 * base groups to drain at the end; expanders behind the last tile cost the scan nothing but
+// run after it.  Measured (S1 / Q_A / Q_B, whole query): at 100 M rows (1.5 k groups) all behind wins (56 / 86 /
+// 105 us against 58 / 96 / 126), at 300 M rows the two are level, at 1 G rows among the tiles wins by 7 - 10 %.
+constexpr uint64_t kInterleaveFromGroups = 4096;
+
+uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group, uint64_t groups) {
     static const char *env = getenv("PQPS_EXPAND_LAG");
     if (env) return (uint32_t)strtoul(env, nullptr, 10);
-    return (uint32_t)ctx->compute_units * 10u / (tiles_per_group + 1u);
+    if (groups < kInterleaveFromGroups) return 0x7FFFFFFFu;         // all behind the last tile
+    return 2u * expand_sum_lag(ctx, tiles_per_group);
 }
 
 uint32_t expand_spin_limit() {
@@ -593,30 +605,37 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         }
         return PQPS_OK;
     }
+    if (ctx->epoch >= 0xFFFFu) {                                 // the tags are about to repeat: start over from "never written"
+        rc = zero_tagged_words(ctx, s);
+        if (rc) return rc;
+        ctx->epoch = 0;
+    }
+    a.epoch = ++ctx->epoch;
     const int half = ctx->parity;
     ctx->parity ^= 1;
-    const HandHalf mine = hand_half(ctx, half), other = hand_half(ctx, half ^ 1);
-    a.gword = mine.gword; a.sword = mine.sword; a.ctl = mine.ctl; a.deferred = mine.deferred;
-    a.zgword = other.gword; a.zsword = other.sword; a.zctl = other.ctl; a.zdeferred = other.deferred;
-    a.zero_groups = ctx->dirty_groups[half ^ 1];
-    ctx->dirty_groups[half ^ 1] = 0;
-    ctx->dirty_groups[half] = groups;
+    a.gsum = ctx->gsum; a.ssum = ctx->ssum; a.deferred = ctx->deferred;
+    a.ctl = ctx->ctl + half * kCtlWords;
+    a.zctl = ctx->ctl + (half ^ 1) * kCtlWords;
     a.base_slot = ctx->base_slot;
     a.status = ctx->status_dev;
     a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
     a.id_base = id_base;
     a.accumulate = gather ? 1u : 0u;
     const uint32_t tiles_per_group = (uint32_t)kGroupSteps / ((uint32_t)kWaves * (a.steps_per_iter ? a.steps_per_iter : 1u));
-    a.lag = expand_lag(ctx, tiles_per_group);
+    a.lag = expand_lag(ctx, tiles_per_group, groups);
+    a.sum_lag = expand_sum_lag(ctx, tiles_per_group);
+    if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
+    if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
     a.spin_limit = expand_spin_limit();
     a.block_base = 0;
-    const uint64_t main_blocks = groups * (tiles_per_group + 1), lag = a.lag < groups ? a.lag : groups;
+    const uint64_t main_blocks = ((groups + 3) / 4) * (4ull * tiles_per_group + 1), lag = trailing_groups((uint32_t)groups, a.lag);
     if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
+    const uint64_t slack = gather ? 4 : 0;                        // gather: the device-side range decides; a smaller range can trail up to 3 more groups
     const bool split = tail != nullptr && tail != s && scan_done != nullptr;
     if (!split) {
         hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
-        if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
-        else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag)), dim3(kBlock), 0, s, a);
+        if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
+        else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, a);
         HIP_TRY(hipGetLastError());
         if (timed) {
             ctx->stop_is_eval[ctx->timed] = true;
@@ -664,10 +683,10 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->scratch_steps = 0;
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->hand = nullptr;
-    ctx->base_slot = nullptr; ctx->partials = nullptr;
+    ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
-    ctx->parity = 0; ctx->dirty_groups[0] = ctx->dirty_groups[1] = 0;
+    ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
