@@ -1,0 +1,109 @@
+"""Kernel variants that the default settings reach only at sizes too large for a bit-exact oracle run, forced at
+small sizes through the shim's switches -- each in its own process, because the shim reads them once.
+
+  * streaming (`nt`) loads for every one of the 34 (W0, W1, W2) shapes, chain and tree form
+  * expanders placed among the scan tiles (the default from 4096 groups = 268 M rows on) with the smallest lags,
+    so that expanders really are early and wait for their tiles, sums and neighbours
+  * the recovery pass: every expander gives up at its first look (spin limit 0), no tile does sum duty -- the
+    last expander publishes every sum and expands every group on its own
+  * a dense answer at > 600 M rows (default placement among the tiles, block and 64-row expansion paths):
+    head and tail of the ID list bit-exact against the host twin, the middle by count and order
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import qpelib as q
+
+pq = q.pq
+pytestmark = pytest.mark.gpu
+DRIVER = str(q.ROOT / "tests" / "variant_driver.py")
+
+
+def run_driver(env, *args, timeout=900):
+    p = subprocess.run([sys.executable, DRIVER, *args], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **env), cwd=str(q.ROOT / "tests"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.stdout[-2000:], p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("nt", ["0", "1"])
+def test_every_shape_with_and_without_streaming_loads(nt):
+    run_driver({"PQPS_NT_LOADS": nt}, "shapes", "70001")
+
+
+def test_streaming_loads_across_sizes():
+    run_driver({"PQPS_NT_LOADS": "1"}, "sizes", "0", "1", "1023", "4097", "100001", str((1 << 21) + 17))
+
+
+@pytest.mark.parametrize("lag,sum_lag", [("0", "1"), ("1", "1"), ("5", "2"), ("40", "20")])
+def test_expanders_among_the_tiles_with_small_lags(lag, sum_lag):
+    run_driver({"PQPS_EXPAND_LAG": lag, "PQPS_SUM_LAG": sum_lag}, "sizes", "1", "4097", "65537", "300001",
+               str((1 << 21) + 17), "9000001")
+
+
+def test_recovery_pass_expands_everything_on_its_own():
+    env = {"PQPS_EXPAND_SPIN_LIMIT": "0", "PQPS_SUM_LAG": "2000000000", "PQPS_EXPAND_LAG": "0"}
+    run_driver(env, "sizes", "1", "65537", "300001", str((1 << 21) + 17))
+    run_driver(dict(env, PQPS_EXPAND_LAG="100000"), "sizes", "300001", "5000001")      # ... and when all expanders trail the tiles
+
+
+def test_dense_answer_above_600m_rows():
+    n = 640_000_003
+    seed = 99
+    ctx = pq.Context(0)
+    dev = pq.SyntheticTable(ctx, n, seed=seed, columns=["sudo_used", "risk_level"])
+    ids_dev, cnt_dev = ctx.malloc(4 * n), ctx.malloc(64)
+    flags_dev = ctx.malloc(n + 4096)
+    try:
+        for chain in ([("sudo_used", "=", "FALSE")], [("risk_level", "<", "3")], [("risk_level", ">", "3")]):
+            pred, cols, nc, _ = dev.bind(chain)
+            pq.check(pq.lib().pqps_filter_scan(ctx.h, cols, nc, n, 0, C.byref(pred), ids_dev, n, cnt_dev, None))
+            ctx.sync()
+            k = C.c_uint64()
+            ctx.download(C.byref(k), cnt_dev, 8)
+            k = k.value
+            pq.check(pq.lib().pqps_filter_count(ctx.h, cols, nc, n, C.byref(pred), cnt_dev, None))
+            ctx.sync()
+            c2 = C.c_uint64()
+            ctx.download(C.byref(c2), cnt_dev, 8)
+            assert k == c2.value and 0 < k < n
+            m = 2_000_000
+            head = q.HostSynth(m, seed=seed).oracle_scan(chain)
+            tail = q.HostSynth(m, seed=seed, row0=n - m).oracle_scan(chain, id_base=n - m).astype(np.uint32)
+            got = np.zeros(len(head) + 1, dtype=np.uint32)
+            ctx.download(got.ctypes.data, ids_dev, got.nbytes)
+            assert np.array_equal(got[:-1], head) and got[-1] >= m
+            got = np.zeros(len(tail) + 1, dtype=np.uint32)
+            ctx.download(got.ctypes.data, ids_dev + 4 * (k - len(tail) - 1), got.nbytes)
+            assert np.array_equal(got[1:], tail) and got[0] < n - m
+            # the middle: strictly ascending over a 64 M-ID window that straddles many groups
+            w = min(k, 64_000_000)
+            mid = np.zeros(w, dtype=np.uint32)
+            ctx.download(mid.ctypes.data, ids_dev + 4 * ((k - w) // 2), mid.nbytes)
+            assert np.all(mid[1:] > mid[:-1])
+        # DELETE flags of a scan that outgrows the Infinity Cache (streaming-load flag kernel)
+        chain = [("sudo_used", "=", "TRUE")]
+        pred, cols, nc, _ = dev.bind(chain)
+        pq.check(pq.lib().pqps_filter_flags(ctx.h, cols, nc, n, C.byref(pred), flags_dev, cnt_dev, None))
+        ctx.sync()
+        kf = C.c_uint64()
+        ctx.download(C.byref(kf), cnt_dev, 8)
+        f = np.zeros(4_000_000, dtype=np.uint8)
+        ctx.download(f.ctypes.data, flags_dev + n - len(f), len(f))
+        want = np.zeros(len(f), dtype=np.uint8)
+        want[q.HostSynth(len(f), seed=seed, row0=n - len(f)).oracle_scan(chain)] = 1
+        assert np.array_equal(f, want)
+        pq.check(pq.lib().pqps_filter_count(ctx.h, cols, nc, n, C.byref(pred), cnt_dev, None))
+        ctx.sync()
+        kc = C.c_uint64()
+        ctx.download(C.byref(kc), cnt_dev, 8)
+        assert kf.value == kc.value
+    finally:
+        for p in (ids_dev, cnt_dev, flags_dev):
+            ctx.free(p)
+        dev.free()
+        ctx.close()
