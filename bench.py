@@ -9,11 +9,15 @@ One "step" = one execution of the hot path: the reference's Sample-1 query shape
     WHERE sudo_used = FALSE AND user_name = "student1030"
 (the query QPESeq really runs through linearSearchRecords over every row, and the one
 BASELINE.md anchors on) over the rank's row-range shard of the seeded synthetic table,
-inputs resident in HBM, through the C-ABI (pqps_filter_scan).  With N > 1 the step
-also merges the matching row IDs of all shards on every rank (count all-gather +
-slot all-gather over RCCL + device compaction), pipelined on a second stream.
-Workload = BASELINE.json configs[1]: 100 M synthetic rows per GPU (weak scaling:
-N GPUs scan N x 100 M rows).  Prints ONE JSON line on rank 0.
+inputs resident in HBM, through the C-ABI (pqps_qstream_scan / pqps_exchange_select).  With N > 1
+the step also merges the matching row IDs of all shards on every rank (RCCL), pipelined on a second
+stream.  Workload = BASELINE.json configs[1]: 100 M synthetic rows per GPU (weak scaling: N GPUs
+scan N x 100 M rows); `--rows-total 1000000000` gives configs[3] (1 B rows sharded over the ranks),
+with `--mode count` configs[4] (COUNT(*) + all-reduce).
+
+The table exists TWICE in HBM and consecutive steps alternate between the copies: a step's 300 MB would
+otherwise find part of itself in the 256 MiB Infinity Cache left by the step before, and the HBM roofline
+would be flattered.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -130,10 +134,15 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
+    ap.add_argument("--rows-total", type=int, default=0,
+                    help="total rows over all ranks (strong scaling, e.g. 1000000000 = configs[3]/[4]); overrides --rows")
+    ap.add_argument("--mode", default="ids", choices=["ids", "count"],
+                    help="ids: ascending row-ID list (+ all-gather merge for N > 1); count: COUNT(*) (+ all-reduce), configs[4]")
+    ap.add_argument("--copies", type=int, default=2, help="table copies the steps alternate between (1: the same buffers every step)")
     ap.add_argument("--query", default="S1", choices=sorted(QUERIES))
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary queries / read probe")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary queries / index / projection / 1 B-row legs")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="N>1 exchange step: 'rccl' = the shim calls ncclAllGather itself (one host call per query); "
@@ -184,12 +193,15 @@ def main():
     assert sptr != 0
 
     chain, sql = QUERIES[args.query]
-    n_global = args.rows * world
+    strong = args.rows_total > 0
+    n_global = args.rows_total if strong else args.rows * world
     start, count = mg.shard_rows(n_global, world, rank)
     if start + count > 2**32:
-        sys.exit("row IDs are u32: rows * gpus must stay below 2^32")
+        sys.exit("row IDs are u32: the table must stay below 2^32 rows")
+    count_mode = args.mode == "count"
+    copies = max(1, args.copies)
 
-    # ---- table: this rank's row range, generated in place on the device -----------------
+    # ---- table: this rank's row range, generated in place on the device, `copies` times -------
     keep = []
 
     def alloc(nbytes):
@@ -199,14 +211,19 @@ def main():
 
     extras = [] if (args.no_extras or world > 1) else [k for k in QUERIES if k != args.query]
     needed = {leaf[0] for k in [args.query] + extras for leaf in _leaves(QUERIES[k][0])} & set(pq.COLUMNS)
-    if extras:
-        needed |= {"command_id", "user_id", "risk_level"}          # index-mode leg (configs[2])
     t0 = time.perf_counter()
-    table = pq.SyntheticTable(ctx, count, seed=args.seed, row0=start, columns=sorted(needed), alloc=alloc, stream=sptr)
+    tables = []
+    for c in range(copies):
+        cols_c = set(needed)
+        if extras and c == 0:
+            cols_c |= {"command_id", "user_id", "risk_level"}      # index-mode leg (configs[2]), first copy only
+        tables.append(pq.SyntheticTable(ctx, count, seed=args.seed, row0=start, columns=sorted(cols_c), alloc=alloc, stream=sptr))
     torch.cuda.synchronize()
-    log(f"{dev_name}, {cus} CUs: generated {count:,} rows x {sorted(needed)} in {time.perf_counter() - t0:.2f} s")
+    log(f"{dev_name}, {cus} CUs: generated {count:,} rows x {sorted(needed)} x {copies} copies in {time.perf_counter() - t0:.2f} s")
 
-    pred, cols, nc, bytes_per_row = table.bind(chain)
+    bound = [t.bind(chain) for t in tables]                         # (pred, cols, n_cols, bytes per row) per copy
+    bytes_per_row = bound[0][3]
+    widths = sorted({tables[0].width[leaf[0]] for leaf in _leaves(chain)}, reverse=True)
     L = pq.lib()
 
     # ---- result buffers (a ring of RING slots for the merge pipeline) ---------------------------
@@ -214,6 +231,7 @@ def main():
     # the data, identical on every step); +25 % head-room, overflow is checked after timing
     cal_ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
     cal_cnt = torch.zeros(1, dtype=torch.int64, device=device)
+    pred, cols, nc, _ = bound[0]
     pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), cal_ids.data_ptr(), count,
                                 cal_cnt.data_ptr(), sptr), "calibration scan")
     torch.cuda.synchronize()
@@ -224,12 +242,13 @@ def main():
         mm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(mm, op=dist.ReduceOp.MAX)
         max_matches = int(mm.item())
-    slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096
+    slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096 if not count_mode else 4096
     del cal_ids
     native = exchange and args.exchange == "rccl" and args.backend == "nccl"
-    # N = 1: a stream of queries -- K2 / K3 of query k run on a second stream under K1 of query k+1
+    # N = 1: a stream of queries -- the expanders behind the last scan tile of query k run on a second
+    # stream under the scan tiles of query k+1
     qs = None
-    if not exchange and not args.no_pipeline:
+    if not exchange and not args.no_pipeline and not count_mode:
         qs = C.c_void_p()
         pq.check(L.pqps_qstream_create(ctx.h, RING, C.byref(qs)), "pqps_qstream_create")
     xch, mergers = None, None
@@ -256,29 +275,47 @@ def main():
         comm = torch.cuda.Stream(device=device)
         filt_done = [torch.cuda.Event() for _ in range(RING)]
         merge_done = [torch.cuda.Event() for _ in range(RING)]
+        count_out = torch.zeros(2 * RING, dtype=torch.int64, device=device)
+        count_all = torch.zeros(RING, dtype=torch.int64, device=cdev)
 
     def step(k):
         r = k % RING
+        pred, cols, nc, _ = bound[k % copies]                       # consecutive steps read different buffers
         if native:
-            # scan on `compute`; all-gather + merge on the exchange's own stream, under the next scans
-            xch.select(cols, nc, count, start, C.byref(pred), r, sptr)
+            # scan on `compute`; the collective (+ merge) on the exchange's own stream, under the next scans
+            if count_mode:
+                xch.count(cols, nc, count, C.byref(pred), r, sptr)
+            else:
+                xch.select(cols, nc, count, start, C.byref(pred), r, sptr)
             return
         m = mergers[r]
-        # slot r is free again once the merge that last used it (query k - RING) has finished: a host-side
-        # wait, normally already satisfied, so the scan stream carries no cross-stream barrier packet
         if qs is not None:
+            # slot r is free again once the query that last used it (k - RING) has finished: a host-side wait
+            # inside the call, normally already satisfied, so the scan stream carries no cross-stream barrier
             pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap, m.count_ptr, sptr),
                      "pqps_qstream_scan")
             return
         merge_done[r].synchronize()
-        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap,
-                                    m.count_ptr, sptr), "pqps_filter_scan")
+        if count_mode:
+            pq.check(L.pqps_filter_count(ctx.h, cols, nc, count, C.byref(pred), count_out[2 * r:].data_ptr(), sptr), "pqps_filter_count")
+        else:
+            pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap,
+                                        m.count_ptr, sptr), "pqps_filter_scan")
         if not exchange:
             return
         filt_done[r].record(compute)
         with torch.cuda.stream(comm):
             comm.wait_event(filt_done[r])
-            m.merge(stream_ptr=comm.cuda_stream)
+            if count_mode:                                          # mpi:745 through torch.distributed
+                if args.backend == "nccl":
+                    count_all[r] = count_out[2 * r]
+                    dist.all_reduce(count_all[r:r + 1])
+                else:
+                    t = count_out[2 * r:2 * r + 1].cpu()
+                    dist.all_reduce(t)
+                    count_all[r] = t[0]
+            else:
+                m.merge(stream_ptr=comm.cuda_stream)
             merge_done[r].record(comm)
 
     def fence():
@@ -287,9 +324,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def ring_wait_ns(reset):
+        if qs is not None:
+            return L.pqps_qstream_wait_ns(qs, reset)
+        if xch is not None:
+            return L.pqps_exchange_wait_ns(xch.h, reset)
+        return 0
+
     for k in range(args.warmup):
         step(k)
     fence()
+    ring_wait_ns(1)
     # ---- timed region: exactly K steps, nothing but the hot path (+ merge) enqueued -------
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -297,11 +342,13 @@ def main():
     enqueued = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
-    log(f"timed region: {elapsed / max(args.steps, 1) * 1e6:.1f} us/step, host enqueue {enqueued / max(args.steps, 1) * 1e6:.1f} us/step")
-    # ---- same K steps again with HIP events around every launch of the evaluate kernel (the
-    # only kernel that reads the table) on its own stream: its average duration feeds
-    # `roofline`.  Kept out of the timed region because an event record costs a few us of
-    # queue time per launch and would distort `value`.
+    waited = ring_wait_ns(1) * 1e-9
+    log(f"timed region: {elapsed / max(args.steps, 1) * 1e6:.1f} us/step; host: {(enqueued - waited) / max(args.steps, 1) * 1e6:.1f} us/step in "
+        f"runtime calls + {waited / max(args.steps, 1) * 1e6:.1f} us/step waiting for a free ring slot (the GPU being the slower side)")
+    # ---- same K steps again with HIP events on the dispatch of every scan kernel (ID output: the ONE launch of
+    # the query -- scan tiles + expanders; COUNT(*): the scan, the 1-workgroup reduction after it in `pipeline`):
+    # its average duration feeds `roofline`.  Kept out of the timed region because in timing mode a query
+    # runs whole on one stream (no overlap with its neighbours), which is not how `value` is produced.
     ctx.set_timing(True)
     for k in range(args.steps):
         step(k)
@@ -314,46 +361,68 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- verify what the timed steps produced ------------------------------------------------
+    # ---- verify what the timed steps produced, on EVERY rank ------------------------------------
+    import numpy as np
     last_slot = (args.steps - 1) % RING if args.steps > 0 else 0
-    if native:
-        merged, got_local = xch.result(last_slot)
-    else:
-        got_local = mergers[last_slot].local_count()
-    assert got_local == local_matches, (got_local, local_matches)
     total_matches = local_matches
     if exchange:
-        if not native:
-            merged = mergers[last_slot].result()
-        import numpy as np
-        assert len(merged) > 0 and bool(np.all(merged[1:] > merged[:-1])), "merged IDs are not strictly ascending"
         tm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(tm)
         total_matches = int(tm.item())
-        assert len(merged) == total_matches, (len(merged), total_matches)
-
+    if count_mode:
+        if native:
+            got_total, got_local = xch.count_result(last_slot)
+        elif exchange:
+            torch.cuda.synchronize()
+            got_total, got_local = int(count_all[last_slot].item()), int(count_out[2 * last_slot].item())
+        else:
+            torch.cuda.synchronize()
+            got_local = int(count_out[2 * last_slot].item())
+            got_total = got_local
+        assert got_local == local_matches and got_total == total_matches, (got_local, local_matches, got_total, total_matches)
+    else:
+        if native:
+            merged, got_local = xch.result(last_slot)
+        else:
+            got_local = mergers[last_slot].local_count()
+        assert got_local == local_matches, (got_local, local_matches)
+        if exchange:
+            if not native:
+                merged = mergers[last_slot].result()
+            assert len(merged) == total_matches, (len(merged), total_matches)
+            assert len(merged) == 0 or bool(np.all(merged[1:] > merged[:-1])), "merged IDs are not strictly ascending"
     rows_per_s = n_global * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     avg_kernel_ms = kern_ms / max(launches, 1)
-    alg_bytes = count * bytes_per_row + 4 * local_matches          # n * sum w(c) + 4 * matches
+    # n * sum w(c) + 4 * matches (ID list) or + 8 (COUNT(*))
+    alg_bytes = count * bytes_per_row + (8 if count_mode else 4 * local_matches)
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
-    traffic, traffic_src = pmc_traffic(args.query, args.rows) if world == 1 else (None, None)
+    traffic, traffic_src = pmc_traffic(args.query, count) if (world == 1 and not count_mode) else (None, None)
+    cfg_no = (4 if count_mode else 3) if strong else 1
+    nt = "true" if count * bytes_per_row > (256 << 20) else "false"
     result = {
         "metric": "rows/sec SELECT-filter on commands_* schema",
         "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: SELECT/WHERE scan-filter on the commands_* schema, {args.rows:,} synthetic rows per GPU",
-                   "query": sql, "rows_per_gpu": args.rows, "rows_total": n_global,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "/".join(f"u{8 * w}" for w in widths), "data": "synthetic",
+        "config": {"workload": (f"configs[{cfg_no}]: " + ("COUNT(*) of the " if count_mode else "") + "SELECT/WHERE scan-filter on the commands_* schema, "
+                                + (f"{n_global:,} synthetic rows sharded over {world} GPU(s)" if strong else f"{args.rows:,} synthetic rows per GPU")),
+                   "query": sql, "mode": args.mode, "rows_per_gpu": count if strong else args.rows, "rows_total": n_global,
                    "matches_total": total_matches, "selectivity": total_matches / n_global,
-                   "bytes_per_row": bytes_per_row,
-                   "pipelining": ("K2/K3 (+ exchange) of query k on a second stream under K1 of query k+1" if (qs is not None or native) else "none: K1, K2, K3 of a query back to back on one stream"),
-                   "parallelism": f"row-range shards x{world}" + (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} [count|IDs] all-gather + device merge per query on every rank ({'shim-driven' if native else 'torch.distributed'})" if exchange else ""),
+                   "bytes_per_row": bytes_per_row, "table_copies_alternated": copies,
+                   "pipelining": ("expanders behind the last scan tile (+ exchange) of query k on a second stream under the scan of query k+1"
+                                  if (qs is not None or native) else "none: the queries back to back on one stream"),
+                   "parallelism": f"row-range shards x{world}" + (
+                       (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} "
+                        + ("all-reduce of the counts" if count_mode else "[count|IDs] all-gather + device merge") + " per query on every rank "
+                        + f"({'shim-driven' if native else 'torch.distributed'})") if exchange else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": K1_NAMES.get(args.query, "eval_spec_kernel / eval_generic_kernel") + " (K1: the only kernel that reads the table)",
+                     "kernel": (K_NAMES.get((args.query, args.mode), "eval_spec_kernel / eval_generic_kernel").replace("NT", "NT=" + nt)
+                                + (" -- the ONE launch of an ID query: scan tiles (the only readers of the table) + expander waves"
+                                   if not count_mode else " -- the scan; the one-workgroup reduction of the totals follows it")),
                      "avg_kernel_ms": avg_kernel_ms, "avg_pipeline_ms": pipe_ms / max(launches, 1),
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
     }
@@ -361,7 +430,7 @@ def main():
     # side measurements must never cost the headline line
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            result["extra"] = extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, extras, log)
+            result["extra"] = extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, extras, log, alloc, args.seed)
         except Exception as e:                                   # noqa: BLE001
             log(f"extras leg failed: {e!r}")
             result["extra"] = {"error": repr(e)}
@@ -386,23 +455,28 @@ def main():
 
 RING = 4      # result slots in flight: query k's merge runs under the scans of queries k+1 ..
 
-# the K1 instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
-K1_NAMES = {"S1": "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT = scan footprint > 320 MiB, VC=false>"}
+# the kernel instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
+K_NAMES = {("S1", "ids"): "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT, VC=false>",
+           ("S1", "count"): "eval_chain_kernel<MODE_COUNT, W0=2, W1=1, W2=0, S=1, NT, VC=false>",
+           ("Q_A", "ids"): "eval_chain_kernel<MODE_IDS, W0=4, W1=0, W2=0, S=1, NT, VC=true>",
+           ("Q_A", "count"): "eval_chain_kernel<MODE_COUNT, W0=4, W1=0, W2=0, S=1, NT, VC=true>",
+           ("Q_B", "ids"): "eval_chain_kernel<MODE_IDS, W0=4, W1=1, W2=0, S=1, NT, VC=false>",
+           ("Q_B", "count"): "eval_chain_kernel<MODE_COUNT, W0=4, W1=1, W2=0, S=1, NT, VC=false>"}
 
 
 def pmc_traffic(query, rows):
-    """HBM bytes per launch of the evaluate kernel from the committed rocprofv3 PMC summary of
+    """HBM bytes per launch of the query's kernel from the committed rocprofv3 PMC summary of
     this same workload (profiles/rNN_<query>_<rows>_pmc.json, made by scripts/profile_pmc.sh +
     scripts/summarize_profiles.py: separate --pmc passes, FETCH_SIZE x 1024 x 2 for the gfx950
     half-count of wide coalesced reads, WRITE_SIZE x 1024).  None when no profile matches."""
     tag = {100_000_000: "100m", 1_000_000_000: "1b"}.get(rows)
     if tag is None:
         return None, None
-    files = sorted((ROOT / "profiles").glob(f"r*_{query.lower()}_{tag}_pmc.json"))
+    files = sorted((ROOT / "profiles").glob(f"r*_{query.lower().replace('_', '')}_{tag}_pmc.json"))
     if not files:
         return None, None
     d = json.loads(files[-1].read_text())
-    k1 = [v for k, v in d.items() if k.startswith("K1_")]
+    k1 = [v for k, v in d.items() if k.startswith("scan_eval_") and "<0," in k]        # the ID-output launch
     if not k1 or "hbm_read_bytes_per_launch" not in k1[0]:
         return None, None
     return k1[0]["hbm_read_bytes_per_launch"] + k1[0].get("hbm_write_bytes_per_launch", 0.0), files[-1].name
@@ -416,42 +490,50 @@ def _leaves(chain):
             yield x
 
 
-def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log):
-    """Untimed-by-the-contract side measurements: other query shapes (kernel-only GB/s),
-    COUNT(*) mode and the plain streaming-read ceiling of this box."""
+def time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps=20):
+    """One query shape, one launch at a time on one stream, HIP events on the dispatch; consecutive launches
+    alternate between the table copies.  -> dict (whole-query numbers; COUNT(*): scan + 1-workgroup reduction)."""
+    bound = [t.bind(chain) for t in tables]
+    bpr = bound[0][3]
+
+    def run(i):
+        pred, cols, nc, _ = bound[i % len(bound)]
+        if mode == "ids":
+            pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), ids.data_ptr(), ids.numel(), cnt.data_ptr(), sptr))
+        else:
+            pq.check(L.pqps_filter_count(ctx.h, cols, nc, count, C.byref(pred), cnt.data_ptr(), sptr))
+    for i in range(4):
+        run(i)
+    torch.cuda.synchronize()
+    ctx.set_timing(True)
+    for i in range(reps):
+        run(i)
+    ms, pipe, k = ctx.kernel_time()
+    ctx.set_timing(False)
+    matches = int(cnt[0].item())
+    byts = count * bpr + (4 * matches if mode == "ids" else 8)       # SURVEY 8(d)
+    return {"rows_per_s": count / (pipe / k * 1e-3), "matches": matches, "bytes_per_row": bpr,
+            "GBps": byts / (pipe / k * 1e-3) / 1e9, "frac_of_8TBps": byts / (pipe / k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "scan_kernel_ms": ms / k, "avg_query_ms": pipe / k}
+
+
+def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log, alloc, seed):
+    """Untimed-by-the-contract side measurements: the other query shapes of SURVEY 8(d) as ID list and as
+    COUNT(*) (whole query, (n * bytes/row + 4 * matches) / time), index probes (configs[2]), device
+    projection, the PCIe-inclusive rate, and the north-star size: S1 / Q_A / Q_B at 1 G rows on this GPU."""
     out = {}
+    table = tables[0]
     ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
     cnt = torch.zeros(2, dtype=torch.int64, device=device)
     reps = 20
     for name in names:
         chain, sql = QUERIES[name]
-        pred, cols, nc, bpr = table.bind(chain)
         for mode in ("ids", "count"):
-            def run():
-                if mode == "ids":
-                    pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), ids.data_ptr(), count, cnt.data_ptr(), sptr))
-                else:
-                    pq.check(L.pqps_filter_count(ctx.h, cols, nc, count, C.byref(pred), cnt.data_ptr(), sptr))
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            ctx.set_timing(True)
-            for _ in range(reps):
-                run()
-            ms, pipe, k = ctx.kernel_time()
-            ctx.set_timing(False)
-            matches = int(cnt[0].item())
-            # K1 alone moves the table bytes; the 4 B per match of the ID list are K3's, so the SURVEY 8(d) figure
-            # n * sum(w) + 4 * matches is set against the whole K1 -> K2 -> K3 time
-            table_bytes = count * bpr
-            byts = table_bytes + (4 * matches if mode == "ids" else 8)
-            out[f"{name}_{mode}"] = {"query": sql, "rows_per_s": count / (pipe / k * 1e-3), "matches": matches,
-                                      "bytes_per_row": bpr, "GBps": table_bytes / (ms / k * 1e-3) / 1e9,
-                                      "frac_of_8TBps": table_bytes / (ms / k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                      "pipeline_GBps": byts / (pipe / k * 1e-3) / 1e9,
-                                      "avg_kernel_ms": ms / k, "avg_pipeline_ms": pipe / k}
-            log(f"{name:>4} {mode:>5}: {out[f'{name}_{mode}']['rows_per_s']/1e9:.1f} G rows/s, "
-                f"{out[f'{name}_{mode}']['GBps']:.0f} GB/s ({100*out[f'{name}_{mode}']['frac_of_8TBps']:.1f} % of 8 TB/s)")
+            r = time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps)
+            r["query"] = sql
+            out[f"{name}_{mode}"] = r
+            log(f"{name:>5} {mode:>5}: {r['avg_query_ms'] * 1e3:7.1f} us  {r['rows_per_s'] / 1e9:7.1f} G rows/s  {r['GBps']:5.0f} GB/s "
+                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s), {r['matches']:,} matches")
     # ---- configs[2]: index range-probe SELECT (sorted-permutation index = B+-tree leaf order) --------
     # bytes per SURVEY 8(d): slice_len * (4 [perm] + sum of gathered predicate column widths) + 4 * matches
     have = set(table.ptr)
@@ -545,20 +627,22 @@ def extras_leg(pq, L, ctx, table, count, start, sptr, torch, device, names, log)
         out[f"{name}_ids_to_host"] = {"query": sql, "matches": m, "ms_per_query": dt * 1e3, "rows_per_s": count / dt,
                                       "note": "blocking: scan + sync + count readback + ID download (pageable host memory)"}
         log(f"{name:>4} ids -> host: {dt * 1e6:.0f} us per query, {count / dt / 1e9:.1f} G rows/s (PCIe-inclusive)")
-    # plain streaming-read ceiling (uint4 load + add), for context next to the 8 TB/s spec
-    nbytes = 2 << 30
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    buf.zero_()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
-        pq.check(L.pqps_read_probe(ctx.h, buf.data_ptr(), nbytes, cnt.data_ptr(), sptr))
-    ev0.record()
-    for _ in range(10):
-        pq.check(L.pqps_read_probe(ctx.h, buf.data_ptr(), nbytes, cnt.data_ptr(), sptr))
-    ev1.record()
-    torch.cuda.synchronize()
-    out["read_probe_GBps"] = nbytes * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
-    log(f"streaming read probe: {out['read_probe_GBps']:.0f} GB/s")
+    # ---- the north-star size on this one GPU: 1 G rows (3 - 5 GB per query: far beyond the Infinity Cache, one copy) ----
+    del ids
+    torch.cuda.empty_cache()
+    n1b = 1_000_000_000
+    big = pq.SyntheticTable(ctx, n1b, seed=seed, row0=0, columns=["sudo_used", "user_name", "risk_level"], alloc=alloc, stream=sptr)
+    ids = torch.empty(n1b // 8, dtype=torch.int32, device=device)
+    ns = {"rows": n1b}
+    for name in ("S1", "Q_A", "Q_B"):
+        chain, sql = QUERIES[name]
+        for mode in ("ids", "count"):
+            r = time_query(pq, L, ctx, [big], chain, mode, n1b, 0, ids, cnt, sptr, torch, reps=10)
+            r["query"] = sql
+            ns[f"{name}_{mode}"] = r
+            log(f"1 G rows {name:>4} {mode:>5}: {r['avg_query_ms'] * 1e3:7.1f} us  {r['rows_per_s'] / 1e12:5.2f} T rows/s  "
+                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s whole query)")
+    out["north_star_1b"] = ns
     return out
 
 

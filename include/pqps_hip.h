@@ -234,6 +234,9 @@ int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols,
                       const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
                       void *scan_stream);
 int pqps_qstream_sync(pqps_qstream *q);
+/* Host time (ns) pqps_qstream_scan has spent waiting for a slot's scratch to come free -- as opposed to time inside
+ * runtime calls; `reset` != 0 clears the counter. */
+uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset);
 int pqps_qstream_destroy(pqps_qstream *q);
 
 /* ---- multi-GPU SELECT: shard scan + ONE RCCL all-gather + device merge, one host call per query ----
@@ -266,6 +269,7 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
 int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
                          uint64_t totals[2]);
 int pqps_exchange_sync(pqps_exchange *x);
+uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset);      /* as pqps_qstream_wait_ns */
 int pqps_exchange_destroy(pqps_exchange *x);
 
 /* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */
@@ -296,10 +300,6 @@ int  pqps_synth_generate(pqps_ctx *ctx, uint64_t seed, uint64_t row0, uint64_t n
 void pqps_synth_generate_host(uint64_t seed, uint64_t row0, uint64_t n,
                               const uint32_t *user_cdf, const uint8_t *user_shell,
                               const pqps_synth_cols *out);
-
-/* Streaming-read probe: sums `bytes` of device memory with 16 B/lane loads;
- * used by bench.py to report the empirical HBM read ceiling next to 8 TB/s. */
-int pqps_read_probe(pqps_ctx *ctx, const void *data, uint64_t bytes, uint64_t *out_sum, void *stream);
 
 #ifdef __cplusplus
 }

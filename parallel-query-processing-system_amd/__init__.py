@@ -241,7 +241,6 @@ def lib():
     L.pqps_synth_generate.argtypes = [vp, u64, u64, u64, vp, vp, C.POINTER(SynthCols), vp]
     L.pqps_synth_generate_host.argtypes = [u64, u64, u64, vp, vp, C.POINTER(SynthCols)]
     L.pqps_synth_generate_host.restype = None
-    L.pqps_read_probe.argtypes = [vp, vp, u64, vp, vp]
     L.pqps_bump_codes.argtypes = [vp, vp, u32, u64, u32, vp]
     L.pqps_compact_rows.argtypes = [vp, C.POINTER(Column), u32, u64, vp, C.POINTER(u64), vp]
     L.pqps_project_column.argtypes = [vp, C.POINTER(Column), vp, vp, u64, u32, vp, vp]
@@ -251,6 +250,10 @@ def lib():
     L.pqps_qstream_create.argtypes = [vp, u32, C.POINTER(vp)]
     L.pqps_qstream_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
     L.pqps_qstream_sync.argtypes = [vp]
+    L.pqps_qstream_wait_ns.argtypes = [vp, C.c_int]
+    L.pqps_qstream_wait_ns.restype = u64
+    L.pqps_exchange_wait_ns.argtypes = [vp, C.c_int]
+    L.pqps_exchange_wait_ns.restype = u64
     L.pqps_qstream_destroy.argtypes = [vp]
     L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
     L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]

@@ -72,6 +72,7 @@ struct EvalArgs {
     uint32_t id_base;
     uint32_t lag;                    // groups between a group's scan tiles and its expander in the grid
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
+    uint32_t trail_quads;            // the expanders behind the last tile are quads as well (one wave per group)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -522,6 +523,7 @@ constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1)
 constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
 constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
 constexpr uint32_t kStageRing = 256;        // >= kDirectIds + 63
+constexpr uint32_t kSoloIds = 256;          // a trailing group with at most this many matches is expanded by its leader wave alone
 constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
 constexpr int kRplShift = 11, kEpochShift = 16, kWordEpochShift = 48;
@@ -593,6 +595,8 @@ __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
         const uint32_t q = b / period, rr = b % period;
         if (rr < quad_tiles) { r.kind = ROLE_SCAN; r.index = q * quad_tiles + rr; }
         else if (q >= lag_quads) { r.kind = ROLE_EXPAND_QUAD; r.index = q - lag_quads; }   // < quads by construction
+    } else if (a.trail_quads) {                                   // a stream of queries: the trailing groups as quads too (see run_filter)
+        if ((b - main_blocks) * 4u < lag) { r.kind = ROLE_EXPAND_QUAD; r.index = quads + (b - main_blocks); }
     } else if (b - main_blocks < lag) {
         r.kind = ROLE_EXPAND_GROUP;
         r.index = groups - lag + (b - main_blocks);
@@ -934,6 +938,28 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     r.head = 0;
     r.pending = 0;
     r.pos = readlane_u64(my_off, (int)__builtin_ctzll(nonempty));   // the range's IDs form one run of the output
+    typedef __attribute__((address_space(1))) const void global_cvoid;
+    typedef __attribute__((address_space(3))) void lds_void;
+    if (__popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
+        // At most 16 non-empty steps in the whole range (a sparse answer): ONE round of loads fetches all their
+        // match words, slot k of the LDS slice = the k-th of them, and they are expanded step by step.
+        const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
+        uint32_t k = 0;
+        for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
+            const uint32_t st = (uint32_t)__builtin_ctzll(rest);
+            if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler does not count LDS-DMA as a write to LDS)
+        k = 0;
+        for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {
+            const uint32_t st = (uint32_t)__builtin_ctzll(rest);
+            const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
+            expand_step<GATHER>(a, ex.begin, g * kGroupSteps + st, sh.mask[park][k][lane], rpl_log2, cwi & kCountMask, lane, ring, r);
+        }
+        if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
     for (uint32_t w0 = c0; w0 < c1; w0 += kGroupSteps / kWaves) {   // 16 steps at a time
         const uint32_t bits = uniform_u32((uint32_t)(nonempty >> w0) & 0xFFFFu);
         if (!bits) continue;
@@ -941,8 +967,6 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
         // step by 32 lanes, no vector register in between), all requested before any is awaited: one memory
         // latency per window.  The slot of an empty step keeps whatever it held: nobody looks at it.
         {
-            typedef __attribute__((address_space(1))) const void global_cvoid;
-            typedef __attribute__((address_space(3))) void lds_void;
             const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + w0) * 64) + lane;
             for (uint32_t rest = bits; rest; rest &= rest - 1) {    // uniform
                 const uint32_t k = (uint32_t)__builtin_ctz(rest);
@@ -1090,10 +1114,18 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
     const bool leader = !shared || wave == 0;
     const uint64_t g = shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave;
-    const uint32_t c0 = shared ? wave * (kGroupSteps / kWaves) : 0u, c1 = shared ? c0 + kGroupSteps / kWaves : (uint32_t)kGroupSteps;
+    if (g >= ex.groups) return;                                     // (the last quad of a table can be short)
+    uint32_t c0 = shared ? wave * (kGroupSteps / kWaves) : 0u, c1 = shared ? c0 + kGroupSteps / kWaves : (uint32_t)kGroupSteps;
     bool ok = false;
     uint32_t cnts = 0;
     uint64_t group_off = 0;
+    if (shared && !leader) {
+        // A group with few matches is its leader's alone: the other three waves leave as soon as they know (from the
+        // group's sum, which a tile has published long ago unless this is the end of the table) -- a wave that waits
+        // at the barrier holds a slot the next query's scan could use.
+        const uint64_t w = ld_sc1(a.gsum + g);
+        if (word_valid(a, w) && (w & kWordMask) <= kSoloIds) return;        // uniform
+    }
     if (leader) {
         uint32_t cw = 0;
         uint64_t psum = 0;
@@ -1104,12 +1136,19 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         }
     }
     if (shared) {
+        const bool solo = ok && wave_sum_u32(cnts & kCountMask) <= kSoloIds;     // (leader's view; the others read sh.state)
         if (leader) {
             sh.counts[lane] = cnts;
-            if (lane == 0) { sh.group_off = group_off; sh.state = ok ? 1u : 0u; }
+            if (lane == 0) { sh.group_off = group_off; sh.state = !ok ? 0u : (solo ? 2u : 1u); }
         }
-        __syncthreads();
-        ok = sh.state != 0u;
+        __syncthreads();                                            // (waves that have left are not waited for)
+        const uint32_t state = sh.state;
+        if (state == 2u) {                                          // few matches: the leader does all 64 steps
+            if (!leader) return;
+            c0 = 0;
+            c1 = kGroupSteps;
+        }
+        ok = state != 0u;
         cnts = sh.counts[lane];
         group_off = sh.group_off;
     }

@@ -13,6 +13,7 @@
 #include <new>
 #include <utility>
 #include <dlfcn.h>
+#include <time.h>
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -245,25 +246,17 @@ __global__ void bump_codes_kernel(T *codes, uint64_t n, uint32_t threshold) {
 // that on a background thread beside its CSV parse -- instead of inside the first query.
 __global__ void warm_kernel() {}
 
-// ---- streaming read probe ----------------------------------------------------
-__global__ __launch_bounds__(256) void read_probe_kernel(const uint4 *p, uint64_t n16, uint64_t *out) {
-    uint64_t acc = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc += (uint64_t)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w
-             + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
-    }
-    for (; i < n16; i += stride) { const uint4 a = p[i]; acc += (uint64_t)a.x + a.y + a.z + a.w; }
-    acc = wave_sum_u64(acc);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
-}
-
 // ---------------------------------------------------------------------------
 // host side of the shim
 // ---------------------------------------------------------------------------
 thread_local char g_err[512] = "";
+
+// host time spent waiting for a ring slot to become free again (as opposed to time inside runtime calls)
+uint64_t now_ns() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -644,12 +637,17 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         }
         return PQPS_OK;
     }
+    // The trailing expanders run beside the NEXT query's scan: what they cost it is the wave slots they hold, not
+    // their own duration (measured: a workgroup per group slows a 100 M-row scan from 46 to 58 us).  So here they
+    // are quads -- one wave per group, four groups per workgroup -- like the expanders among the tiles.
+    a.trail_quads = 1;
     hipExtLaunchKernelGGL(k1, dim3((uint32_t)main_blocks), dim3(kBlock), 0, s, nullptr, scan_done, 0, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamWaitEvent(tail, scan_done, 0));
     a.block_base = main_blocks;
-    if (done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)lag), dim3(kBlock), 0, tail, nullptr, done, 0, a);
-    else hipLaunchKernelGGL(k1, dim3((uint32_t)lag), dim3(kBlock), 0, tail, a);
+    const uint32_t tail_blocks = (uint32_t)((lag + 3) / 4);
+    if (done) hipExtLaunchKernelGGL(k1, dim3(tail_blocks), dim3(kBlock), 0, tail, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k1, dim3(tail_blocks), dim3(kBlock), 0, tail, a);
     HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }
@@ -1281,6 +1279,7 @@ struct pqps_exchange {
     hipEvent_t *scan_done, *k1_done, *merge_done;
     pqps_ctx **child;                // [ring] a context (= filter scratch) per query in flight
     bool *used;
+    uint64_t wait_ns;                // host time spent waiting for a slot to come free
 };
 
 int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id) {
@@ -1362,7 +1361,7 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
     // the slot is free again once the merge that last used it has finished (a host wait, normally
     // long satisfied: the scan stream carries no cross-stream barrier)
-    if (x->used[slot]) HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    if (x->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(x->merge_done[slot])); x->wait_ns += now_ns() - t0; }
     uint32_t *local = x->local + (uint64_t)slot * x->stride;
     uint32_t *slots = x->slots + (uint64_t)slot * x->world * x->stride;
     hipStream_t scan = pick_stream(x->ctx, scan_stream);
@@ -1397,7 +1396,7 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
                         const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
-    if (x->used[slot]) HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    if (x->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(x->merge_done[slot])); x->wait_ns += now_ns() - t0; }
     uint32_t *local = x->local + (uint64_t)slot * x->stride;
     uint64_t *totals = x->totals + 2 * (uint64_t)slot;
     hipStream_t scan = pick_stream(x->ctx, scan_stream);
@@ -1432,6 +1431,13 @@ int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merge
     return PQPS_OK;
 }
 
+uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset) {
+    if (!x) return 0;
+    const uint64_t w = x->wait_ns;
+    if (reset) x->wait_ns = 0;
+    return w;
+}
+
 int pqps_exchange_sync(pqps_exchange *x) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
     HIP_TRY(hipStreamSynchronize(x->stream));
@@ -1447,6 +1453,7 @@ struct pqps_qstream {
     pqps_ctx **child;                // [depth] scratch of the queries in flight
     hipEvent_t *k1_done, *done;
     bool *used;
+    uint64_t wait_ns;                // host time spent waiting for a slot's scratch to come free
 };
 
 int pqps_qstream_destroy(pqps_qstream *q) {
@@ -1495,7 +1502,7 @@ int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols,
     const uint32_t slot = (uint32_t)(q->seq % q->depth);
     // this slot's scratch is free once the compaction that last used it has finished (a host wait,
     // `depth` queries back -- normally long satisfied)
-    if (q->used[slot]) HIP_TRY(hipEventSynchronize(q->done[slot]));
+    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->done[slot])); q->wait_ns += now_ns() - t0; }
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
@@ -1509,20 +1516,16 @@ int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols,
     return PQPS_OK;
 }
 
+uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset) {
+    if (!q) return 0;
+    const uint64_t w = q->wait_ns;
+    if (reset) q->wait_ns = 0;
+    return w;
+}
+
 int pqps_qstream_sync(pqps_qstream *q) {
     if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
     HIP_TRY(hipStreamSynchronize(q->compact));
-    return PQPS_OK;
-}
-
-int pqps_read_probe(pqps_ctx *ctx, const void *data, uint64_t bytes, uint64_t *out_sum, void *stream) {
-    if (!ctx || !data || !out_sum) return fail(PQPS_EINVAL, "NULL argument");
-    if (((uintptr_t)data & 15u) != 0) return fail(PQPS_EINVAL, "data not 16-byte aligned");
-    hipStream_t s = pick_stream(ctx, stream);
-    HIP_TRY(hipMemsetAsync(out_sum, 0, sizeof(uint64_t), s));
-    const uint32_t blocks = (uint32_t)ctx->compute_units * 8u;
-    hipLaunchKernelGGL(read_probe_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)data, bytes / 16, out_sum);
-    HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }
 

@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel-trace stats of one bench.py run; CSVs land in gpurun_out/prof_<tag>/
+# (pass --no-pipeline to have every launch of the scan kernel be one whole query, as in bench.py's roofline leg)
 # usage: scripts/profile_bench.sh <tag> [extra bench.py args]
 tag=${1:-r01}; shift
 cd /tmp && export TMPDIR=/tmp

@@ -22,11 +22,10 @@ OUT = ROOT / "profiles"
 
 
 def short(name):
-    for key, tag in (("eval_chain_kernel", "K1_eval_chain"), ("eval_spec_kernel", "K1_eval_spec"), ("eval_generic_kernel", "K1_eval_generic"),
-                     ("group_sum_kernel", "K2_group_sum"), ("expand_kernel", "K3_expand"),
+    for key, tag in (("eval_chain_kernel", "scan_eval_chain"), ("eval_spec_kernel", "scan_eval_spec"), ("eval_generic_kernel", "scan_eval_generic"),
                      ("reduce_totals_kernel", "reduce_totals"), ("merge_slots_kernel", "merge_slots")):
         if key in name:
-            if key in ("eval_spec_kernel", "eval_chain_kernel"):
+            if key in ("eval_spec_kernel", "eval_chain_kernel", "eval_generic_kernel"):
                 return tag + name[name.index("<"):name.index(">") + 1].replace(" ", "")
             return tag
     return None
