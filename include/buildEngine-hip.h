@@ -63,7 +63,18 @@ struct hipTable {
     record *row_block;                           /* contiguous host rows (all_records[i] point in) */
     size_t row_capacity;                         /* rows row_block / all_records have room for      */
     struct hipLocks *locks;                      /* engine tables only; NULL for ad-hoc tables      */
+    /* Several devices in one process (PQPS_DEVICES=0,1,...): the engine's rows are split into contiguous
+     * shards by the reference's block partition (executeEngine-mpi.c:703-715), one device table each.
+     * shard[0] is this table; it alone owns the dictionaries (codes are global), the host rows and the
+     * locks.  A table without shards (n_shards 0) is its own single shard. */
+    int n_shards;
+    struct hipTable **shard;
+    uint64_t row0;                               /* engine row number of this shard's first row    */
 };
+
+#define HIP_MAX_SHARDS 16
+static inline int hipTableShards(const struct hipTable *t) { return t->n_shards > 1 ? t->n_shards : 1; }
+static inline struct hipTable *hipTableShard(struct hipTable *t, int s) { return t->n_shards > 1 ? t->shard[s] : t; }
 
 /* No-ops on a table without locks. */
 void hipTableLockShared(struct hipTable *t);
@@ -94,11 +105,11 @@ bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *futu
 /* Re-creates columns, dictionaries and indexes from engine->all_records
  * (after INSERT / DELETE changed the host rows). */
 void rebuildDeviceTableHIP(struct engineS *engine);
-/* INSERT: appends engine->all_records[num_records-1] to the device table in place. */
+/* INSERT: appends engine->all_records[num_records-1] to the device table (its last shard) in place. */
 void appendRowDeviceTableHIP(struct engineS *engine);
-/* DELETE: `delete_flags_dev` (1 = row goes, from pqps_filter_flags) compacts the device columns
- * in place; `expected_rows` = survivors counted on the host (cross-check). */
-void compactDeviceTableHIP(struct engineS *engine, const uint8_t *delete_flags_dev, size_t expected_rows);
+/* DELETE: `delete_flags_dev[s]` (1 = row goes, from pqps_filter_flags on shard s) compacts that shard's
+ * device columns in place; `expected_rows` = survivors counted on the host over all shards (cross-check). */
+void compactDeviceTableHIP(struct engineS *engine, uint8_t *const *delete_flags_dev, size_t expected_rows);
 void destroyDeviceTableHIP(struct engineS *engine);
 
 /* Lower-level pieces (also used for ad-hoc tables over caller-supplied rows,

@@ -16,8 +16,10 @@
  * Results are bit-exact with QPESeq (the serial engine): scan mode returns
  * ascending row order; index mode returns (key asc, row desc) per probed
  * top-level condition, concatenated, then re-filtered.
- * The engine fails loudly (stderr + exit) if no gfx950 device / HIP runtime
- * is available: there is no CPU fallback.
+ * There is no CPU fallback: without a gfx950 device / the HIP runtime
+ * initializeEngineHIP prints the reason and exits, like the reference's engines on a failed start-up
+ * allocation.  A query that fails later (a WHERE that cannot be compiled, a device error) prints the reason
+ * and reports failure -- success = false / -1 -- and the engine stays usable.
  */
 #ifndef EXECUTE_ENGINE_HIP_H
 #define EXECUTE_ENGINE_HIP_H
@@ -76,8 +78,10 @@ struct hipColumnarResult {
     char **columnNames;
     int *columnKinds;                  /* HIPKIND_U64 / _I32 / _BOOL / _DICT (hipPredicate.h); -1 = unknown column ("NULL" cells) */
     void **values;                     /* per column, numRecords entries: uint64_t / int32_t / uint8_t / uint32_t dictionary code */
-    const char *const **dictionaries;  /* per column: code -> C string for _DICT columns (owned by the engine: valid until it is
-                                          modified by INSERT / DELETE or destroyed), else NULL */
+    const char *const **dictionaries;  /* per column: code -> C string for _DICT columns, else NULL.  Owned by the result: the
+                                          codes are numbered 0 .. dictionarySizes[col]-1 over the distinct values this result
+                                          holds, ascending in strcmp order */
+    int *dictionarySizes;
     double queryTime;                  /* selection + device gather + download */
     bool success;
 };
@@ -91,6 +95,10 @@ char *hipColumnarCellText(const struct hipColumnarResult *result, int row, int c
  * free it with freeResultSetHead. */
 struct resultSetS *hipColumnarHead(const struct hipColumnarResult *result, int limit);
 void freeResultSetHead(struct resultSetS *head, int rows);
+
+/* Number of device shards the engine's table is split into (1 unless PQPS_DEVICES names several devices);
+ * `rows` (may be NULL, room for that many entries) receives the rows each shard holds. */
+int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity);
 
 /* COUNT(*) through the backend API (the reference parser cannot express it,
  * SURVEY.md fact 10): scan-mode count of matching rows, no ID list. */

@@ -50,6 +50,23 @@ int hipCompileWhere(const struct hipSchema *schema, const struct whereClauseS *w
                     pqps_predicate *pred, int column_ids[PQPS_MAX_COLUMNS],
                     char *err, size_t errlen);
 
+/* A WHERE of any size as a sequence of passes.  Pass k < n_passes - 1 is evaluated into one flag byte per row
+ * (pqps_filter_flags); a later pass reads those flags as a 1-byte column: column id PQPS_MAX_COLUMNS + k in its
+ * column_ids.  The last pass yields the query's result.  Nearly every clause is a single pass; a clause with
+ * more than PQPS_MAX_LEAVES reachable comparisons (or more than PQPS_MAX_COLUMNS columns once flags are
+ * counted) is split along the reference's own evaluation order (evaluateWhereClause, serial:292-316). */
+struct hipPass {
+    pqps_predicate pred;
+    int column_ids[PQPS_MAX_COLUMNS];
+};
+struct hipPlan {
+    int n_passes;
+    struct hipPass *pass;        /* malloc'd; hipPlanFree */
+};
+int hipCompileWherePlan(const struct hipSchema *schema, const struct whereClauseS *where,
+                        struct hipPlan *plan, char *err, size_t errlen);
+void hipPlanFree(struct hipPlan *plan);
+
 /* Column name -> HIPCOL_* id, -1 if unknown. */
 int hipColumnId(const char *name);
 

@@ -91,6 +91,25 @@ long long refh_select(void *e, const char *sql, char *out, long long cap) {
     return (long long)b.len;
 }
 
+/* The engine API below the parser: executeQuerySelectSerial on a caller-built whereClauseS list (the parser
+ * takes at most 5 conditions per level; the backend takes any list).  Same serialisation as refh_select. */
+long long refh_select_where(void *e, const char **items, int n_items, struct whereClauseS *wc, char *out, long long cap) {
+    struct resultSetS *rs = executeQuerySelectSerial((struct engineS *)e, items, n_items, "commands", wc);
+    struct sbuf b = { out, 0, (size_t)cap };
+    if (cap > 0) out[0] = '\0';
+    sb_int(&b, rs->numRecords); sb_put(&b, US);
+    sb_int(&b, rs->numColumns); sb_put(&b, US);
+    sb_put(&b, rs->success ? "1" : "0"); sb_put(&b, RS);
+    for (int j = 0; j < rs->numColumns; j++) { sb_put(&b, rs->columnNames[j]); sb_put(&b, US); }
+    sb_put(&b, RS);
+    for (int i = 0; i < rs->numRecords; i++) {
+        for (int j = 0; j < rs->numColumns; j++) { sb_put(&b, rs->data[i][j]); sb_put(&b, US); }
+        sb_put(&b, RS);
+    }
+    freeResultSet(rs);
+    return (long long)b.len;
+}
+
 /* Same chain, result printed by the reference's printTable into `path`. */
 int refh_print(void *e, const char *sql, int limit, const char *path) {
     Token tokens[MAX_TOKENS];

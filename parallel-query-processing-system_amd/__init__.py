@@ -90,7 +90,8 @@ class ColumnarResult(C.Structure):
     """struct hipColumnarResult (include/executeEngine-hip.h)."""
     _fields_ = [("numRecords", C.c_int), ("numColumns", C.c_int), ("columnNames", C.POINTER(C.c_char_p)),
                 ("columnKinds", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_void_p)),
-                ("dictionaries", C.POINTER(C.POINTER(C.c_char_p))), ("queryTime", C.c_double), ("success", C.c_bool)]
+                ("dictionaries", C.POINTER(C.POINTER(C.c_char_p))), ("dictionarySizes", C.POINTER(C.c_int)),
+                ("queryTime", C.c_double), ("success", C.c_bool)]
 
 
 class EngineS(C.Structure):
@@ -126,6 +127,15 @@ class Predicate(C.Structure):
         ("on_false", C.c_uint8 * MAX_LEAVES),
         ("order", C.c_uint8 * MAX_LEAVES),
     ]
+
+
+class Pass(C.Structure):
+    """struct hipPass (include/hipPredicate.h)."""
+    _fields_ = [("pred", Predicate), ("column_ids", C.c_int * MAX_COLUMNS)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("n_passes", C.c_int), ("passes", C.POINTER(Pass))]
 
 
 class SynthCols(C.Structure):
@@ -263,6 +273,9 @@ def lib():
     L.pqps_exchange_sync.argtypes = [vp]
     L.pqps_exchange_destroy.argtypes = [vp]
     L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    L.hipCompileWherePlan.argtypes = [C.POINTER(Schema), W, C.POINTER(Plan), C.c_char_p, C.c_size_t]
+    L.hipPlanFree.argtypes = [C.POINTER(Plan)]
+    L.hipPlanFree.restype = None
     L.hipColumnId.argtypes = [C.c_char_p]
     for name in ("hipDumpTokens", "hipDumpParse"):
         f = getattr(L, name)
@@ -278,6 +291,8 @@ def lib():
     L.executeQuerySelectHIP.argtypes = [E, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, W]
     L.executeQuerySelectIdsHIP.restype = C.c_longlong
     L.executeQuerySelectIdsHIP.argtypes = [E, W, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_double)]
+    L.hipEngineShards.restype = C.c_int
+    L.hipEngineShards.argtypes = [E, C.POINTER(C.c_ulonglong), C.c_int]
     L.executeQueryCountHIP.restype = C.c_longlong
     L.executeQueryCountHIP.argtypes = [E, W]
     CR = C.POINTER(ColumnarResult)
@@ -341,6 +356,24 @@ class SchemaSpec:
         c = self.schema.col[COL[name]]
         c.present, c.width, c.dict_count, c.dict = 1, width, len(values), arr
         return self
+
+
+def compile_plan(spec: SchemaSpec, chain):
+    """-> [(Predicate, [column id per slot]), ...]: the passes of hipCompileWherePlan.  A column id >= MAX_COLUMNS
+    names the flags of pass (id - MAX_COLUMNS); the last pass is the query's result."""
+    wl = WhereList(chain)
+    plan = Plan()
+    err = C.create_string_buffer(200)
+    rc = lib().hipCompileWherePlan(C.byref(spec.schema), wl.ptr, C.byref(plan), err, 200)
+    if rc != 0:
+        raise PqpsError("hipCompileWherePlan: " + err.value.decode())
+    out = []
+    for k in range(plan.n_passes):
+        pred = Predicate()
+        C.memmove(C.byref(pred), C.byref(plan.passes[k].pred), C.sizeof(Predicate))
+        out.append((pred, list(plan.passes[k].column_ids[:pred.n_columns])))
+    lib().hipPlanFree(C.byref(plan))
+    return out
 
 
 def compile_where(spec: SchemaSpec, chain):
@@ -508,6 +541,12 @@ class HipEngine:
         out = list(ids[:k])
         lib().free(ids)
         return out
+
+    def shards(self):
+        """Rows held by each device shard (one entry unless PQPS_DEVICES names several devices)."""
+        rows = (C.c_ulonglong * 16)()
+        k = lib().hipEngineShards(self.e, rows, 16)
+        return list(rows[:k])
 
     def count(self, chain):
         wl = WhereList(chain)

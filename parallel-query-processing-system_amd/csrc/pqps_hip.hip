@@ -309,7 +309,12 @@ struct pqps_ctx {
 
 namespace {
 
-hipStream_t pick_stream(pqps_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+// Every entry point that launches or copies comes through here: one process may hold contexts on several
+// devices (the engine's PQPS_DEVICES shards), and kernels / allocations go to the calling thread's current device.
+hipStream_t pick_stream(pqps_ctx *ctx, void *stream) {
+    (void)hipSetDevice(ctx->device);
+    return stream ? (hipStream_t)stream : ctx->stream;
+}
 
 void free_scratch(pqps_ctx *ctx) {
     void *all[] = {ctx->masks, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials};

@@ -348,51 +348,114 @@ static void *col_thread(void *p) {
 
 /* The HIP runtime takes ~0.2 s to come up; an engine that is about to parse a CSV starts that in the
  * background (hipBeginContextHIP) and collects the context when the first device call is due. */
-struct hipContextFuture { pthread_t tid; bool threaded; pqps_ctx *ctx; int rc; int device; char err[256]; };
+struct hipContextFuture {
+    pthread_t tid; bool threaded;
+    int n; int device[HIP_MAX_SHARDS]; pqps_ctx *ctx[HIP_MAX_SHARDS];
+    int rc; char err[256];
+};
 
 static void *context_thread(void *p) {
     struct hipContextFuture *f = p;
-    f->rc = pqps_ctx_create(f->device, &f->ctx);
-    if (f->rc != PQPS_OK) snprintf(f->err, sizeof f->err, "%s", pqps_last_error());   /* last_error is per thread */
+    for (int i = 0; i < f->n; i++) {
+        f->rc = pqps_ctx_create(f->device[i], &f->ctx[i]);
+        if (f->rc != PQPS_OK) {
+            snprintf(f->err, sizeof f->err, "device %d: %s", f->device[i], pqps_last_error());   /* last_error is per thread */
+            for (int k = 0; k < i; k++) { pqps_ctx_destroy(f->ctx[k]); f->ctx[k] = NULL; }
+            break;
+        }
+    }
     return NULL;
+}
+
+/* PQPS_DEVICES=0,1,... : one shard of the table per listed device (a device may be listed more than once:
+ * its shards then share the card).  Otherwise PQPS_DEVICE (default 0) holds the whole table. */
+static int device_list(int *device) {
+    const char *list = getenv("PQPS_DEVICES");
+    int n = 0;
+    if (list && *list) {
+        const char *p = list;
+        while (*p && n < HIP_MAX_SHARDS) {
+            char *end = NULL;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            device[n++] = (int)d;
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
+        }
+    }
+    if (n == 0) {
+        const char *env = getenv("PQPS_DEVICE");
+        device[n++] = env ? atoi(env) : 0;
+    }
+    return n;
 }
 
 struct hipContextFuture *hipBeginContextHIP(void) {
     struct hipContextFuture *f = calloc(1, sizeof *f);
     if (!f) { perror("Failed to allocate memory for device start-up"); exit(EXIT_FAILURE); }
-    const char *env = getenv("PQPS_DEVICE");
-    f->device = env ? atoi(env) : 0;
+    f->n = device_list(f->device);
     f->threaded = pthread_create(&f->tid, NULL, context_thread, f) == 0;
     if (!f->threaded) context_thread(f);
     return f;
 }
 
-static pqps_ctx *await_context(struct hipContextFuture *f) {
+static void await_contexts(struct hipContextFuture *f) {
     if (f->threaded) { pthread_join(f->tid, NULL); f->threaded = false; }
     if (f->rc != PQPS_OK) {
         fprintf(stderr, "HIP engine: cannot create a device context: %s\n", f->err);
         exit(EXIT_FAILURE);
     }
-    return f->ctx;
 }
 
-static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *future, record *const *rows, size_t n);
+/* Columns of `n` host rows staged on the host (dictionaries built), then uploaded as `n_shards` contiguous
+ * row ranges, one per context. */
+static void table_fill(struct hipTable *t, pqps_ctx *const *ctxs, int n_shards, struct hipContextFuture *future,
+                       record *const *rows, size_t n);
 
-struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) { return table_from_rows(ctx, NULL, rows, n); }
-
-/* Builds a device table from `n` host rows.  ctx may be shared (owned by the caller).
- * Capacity leaves head-room so that INSERT appends in place. */
-static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *future, record *const *rows, size_t n) {
+struct hipTable *hipTableFromRows(pqps_ctx *ctx, record *const *rows, size_t n) {
     struct hipTable *t = calloc(1, sizeof *t);
     if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
-    t->ctx = ctx;
-    t->n_rows = n;
-    t->capacity_rows = (n + n / 16 + PQPS_TILE_ROWS) / PQPS_TILE_ROWS * PQPS_TILE_ROWS;
+    table_fill(t, &ctx, 1, NULL, rows, n);
+    return t;
+}
+
+/* Block partition of executeEngine-mpi.c:703-715: the first n % parts shards hold one row more. */
+static void shard_range(size_t n, int parts, int s, size_t *start, size_t *count) {
+    const size_t base = n / (size_t)parts, rem = n % (size_t)parts;
+    *start = (size_t)s * base + ((size_t)s < rem ? (size_t)s : rem);
+    *count = base + ((size_t)s < rem ? 1 : 0);
+}
+
+/* Device side of one shard: rows [row0, row0 + count) of the staged columns.  Capacity leaves head-room so
+ * that INSERT appends in place; the rows past the last one are zero (the filter reads whole 1024-row steps). */
+static void shard_upload(struct hipTable *sh, pqps_ctx *ctx, const struct hipTable *widths, void *const *stage,
+                         size_t row0, size_t count) {
+    sh->ctx = ctx;
+    sh->n_rows = count;
+    sh->row0 = row0;
+    sh->capacity_rows = (count + count / 16 + PQPS_TILE_ROWS) / PQPS_TILE_ROWS * PQPS_TILE_ROWS;
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        const uint32_t width = widths->col[c].width;
+        void *dev = NULL;
+        if (pqps_malloc(ctx, sh->capacity_rows * width, &dev) != PQPS_OK) hip_die("column allocation");
+        if (pqps_memset(ctx, dev, 0, sh->capacity_rows * width, NULL) != PQPS_OK) hip_die("column clear");
+        if (count && pqps_upload(ctx, dev, (const char *)stage[c] + row0 * width, count * width, NULL) != PQPS_OK) hip_die("column upload");
+        sh->col[c].data = dev;
+        sh->col[c].width = width;
+    }
+    sh->capacity_ids = sh->capacity_rows;
+    if (pqps_malloc(ctx, sh->capacity_ids * sizeof(uint32_t), (void **)&sh->ids_dev) != PQPS_OK) hip_die("result allocation");
+    if (pqps_malloc(ctx, 8 * sizeof(uint64_t), (void **)&sh->count_dev) != PQPS_OK) hip_die("counter allocation");
+    if (pqps_ctx_reserve(ctx, sh->capacity_rows) != PQPS_OK) hip_die("filter scratch allocation");   /* not inside the first query */
+}
+
+static void table_fill(struct hipTable *t, pqps_ctx *const *ctxs, int n_shards, struct hipContextFuture *future,
+                       record *const *rows, size_t n) {
     struct col_job job;
     memset(&job, 0, sizeof job);
-    job.rows = rows; job.n = n; job.cap_rows = t->capacity_rows; job.t = t;
+    job.rows = rows; job.n = n; job.cap_rows = n; job.t = t;
     for (int c = 0; c < HIPCOL_COUNT; c++) {
-        job.stage[c] = calloc(t->capacity_rows, 8);
+        job.stage[c] = malloc((n ? n : 1) * 8);
         if (!job.stage[c]) { perror("Failed to allocate staging memory"); exit(EXIT_FAILURE); }
     }
     /* one thread per column (12 independent tasks); tiny tables stay on the caller's thread */
@@ -408,20 +471,31 @@ static struct hipTable *table_from_rows(pqps_ctx *ctx, struct hipContextFuture *
         for (int c = 0; c < HIPCOL_COUNT; c++) if (tid[c]) pthread_join(tid[c], NULL);
     }
     if (job.failed) { perror("Failed to build dictionary"); exit(EXIT_FAILURE); }
-    if (!ctx) { ctx = await_context(future); t->ctx = ctx; }   /* host staging above ran beside the device start-up */
-    for (int c = 0; c < HIPCOL_COUNT; c++) {
-        const uint32_t width = t->col[c].width;
-        void *dev = NULL;
-        if (pqps_malloc(ctx, t->capacity_rows * width, &dev) != PQPS_OK) hip_die("column allocation");
-        if (pqps_upload(ctx, dev, job.stage[c], t->capacity_rows * width, NULL) != PQPS_OK) hip_die("column upload");
-        t->col[c].data = dev;
-        free(job.stage[c]);
+    if (future) {                                           /* host staging above ran beside the device start-up */
+        await_contexts(future);
+        ctxs = future->ctx;
+        n_shards = future->n;
     }
-    t->capacity_ids = t->capacity_rows;
-    if (pqps_malloc(ctx, t->capacity_ids * sizeof(uint32_t), (void **)&t->ids_dev) != PQPS_OK) hip_die("result allocation");
-    if (pqps_malloc(ctx, 8 * sizeof(uint64_t), (void **)&t->count_dev) != PQPS_OK) hip_die("counter allocation");
-    if (pqps_ctx_reserve(ctx, t->capacity_rows) != PQPS_OK) hip_die("filter scratch allocation");   /* not inside the first query */
-    return t;
+    t->n_shards = 0;
+    t->shard = NULL;
+    if (n_shards > 1) {
+        t->shard = calloc((size_t)n_shards, sizeof *t->shard);
+        if (!t->shard) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+        t->n_shards = n_shards;
+        t->shard[0] = t;
+    }
+    for (int s = 0; s < n_shards; s++) {
+        struct hipTable *sh = t;
+        if (s > 0) {
+            sh = calloc(1, sizeof *sh);
+            if (!sh) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+            t->shard[s] = sh;
+        }
+        size_t row0, count;
+        shard_range(n, n_shards, s, &row0, &count);
+        shard_upload(sh, ctxs[s], t, job.stage, row0, count);
+    }
+    for (int c = 0; c < HIPCOL_COUNT; c++) free(job.stage[c]);
 }
 
 static void dictionary_free(struct hipDictionary *d) {
@@ -447,21 +521,38 @@ void hipTableUnlock(struct hipTable *t) { if (t && t->locks) pthread_rwlock_unlo
 void hipTableLockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_lock(&t->locks->device); }
 void hipTableUnlockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_unlock(&t->locks->device); }
 
-/* Frees what the table owns on the device and its dictionaries, not the struct itself. */
-static void table_release(struct hipTable *t, int n_indexes) {
+/* Device buffers of one shard. */
+static void shard_release(struct hipTable *sh, int n_indexes) {
     for (int c = 0; c < HIPCOL_COUNT; c++) {
-        if (t->col[c].data) pqps_free(t->ctx, (void *)t->col[c].data);
-        dictionary_free(&t->dict[c]);
+        if (sh->col[c].data) pqps_free(sh->ctx, (void *)sh->col[c].data);
+        sh->col[c].data = NULL;
     }
-    if (t->index) {
+    if (sh->index) {
         for (int i = 0; i < n_indexes; i++) {
-            if (t->index[i].perm_dev) pqps_free(t->ctx, t->index[i].perm_dev);
-            if (t->index[i].keys_dev) pqps_free(t->ctx, t->index[i].keys_dev);
+            if (sh->index[i].perm_dev) pqps_free(sh->ctx, sh->index[i].perm_dev);
+            if (sh->index[i].keys_dev) pqps_free(sh->ctx, sh->index[i].keys_dev);
         }
-        free(t->index);
+        free(sh->index);
+        sh->index = NULL;
     }
-    if (t->ids_dev) pqps_free(t->ctx, t->ids_dev);
-    if (t->count_dev) pqps_free(t->ctx, t->count_dev);
+    if (sh->ids_dev) pqps_free(sh->ctx, sh->ids_dev);
+    if (sh->count_dev) pqps_free(sh->ctx, sh->count_dev);
+    sh->ids_dev = NULL;
+    sh->count_dev = NULL;
+}
+
+/* Frees what the table owns on its devices, its dictionaries and its peer shards -- not the struct
+ * itself, not the contexts. */
+static void table_release(struct hipTable *t, int n_indexes) {
+    for (int s = hipTableShards(t) - 1; s >= 0; s--) {
+        struct hipTable *sh = hipTableShard(t, s);
+        shard_release(sh, n_indexes);
+        if (sh != t) free(sh);
+    }
+    free(t->shard);
+    t->shard = NULL;
+    t->n_shards = 0;
+    for (int c = 0; c < HIPCOL_COUNT; c++) dictionary_free(&t->dict[c]);
 }
 
 void hipTableFree(struct hipTable *t, int n_indexes) {
@@ -475,7 +566,7 @@ void hipTableFree(struct hipTable *t, int n_indexes) {
     free(t);
 }
 
-/* Device index for engine->indexed_attributes[slot]. */
+/* Device index of one shard for engine->indexed_attributes[slot]: row numbers are shard-local. */
 static bool build_index(struct engineS *engine, struct hipTable *t, int slot) {
     struct hipIndex *ix = &t->index[slot];
     memset(ix, 0, sizeof *ix);
@@ -498,8 +589,7 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
     engine->bplus_tree_roots = realloc(engine->bplus_tree_roots, (size_t)(slot + 1) * sizeof(node *));
     engine->indexed_attributes = realloc(engine->indexed_attributes, (size_t)(slot + 1) * sizeof(char *));
     engine->attribute_types = realloc(engine->attribute_types, (size_t)(slot + 1) * sizeof(FieldType));
-    t->index = realloc(t->index, (size_t)(slot + 1) * sizeof *t->index);
-    if (!engine->bplus_tree_roots || !engine->indexed_attributes || !engine->attribute_types || !t->index) {
+    if (!engine->bplus_tree_roots || !engine->indexed_attributes || !engine->attribute_types) {
         perror("Failed to allocate memory for engine components");
         exit(EXIT_FAILURE);
     }
@@ -507,7 +597,14 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
     engine->indexed_attributes[slot] = strdup(indexName);
     engine->attribute_types[slot] = mapAttributeTypeHIP(attributeType);
     engine->num_indexes = slot + 1;
-    return build_index(engine, t, slot);
+    bool ok = true;
+    for (int s = 0; s < hipTableShards(t); s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        sh->index = realloc(sh->index, (size_t)(slot + 1) * sizeof *sh->index);
+        if (!sh->index) { perror("Failed to allocate memory for engine components"); exit(EXIT_FAILURE); }
+        ok = build_index(engine, sh, slot) && ok;
+    }
+    return ok;
 }
 
 bool buildDeviceTableHIP(struct engineS *engine) {
@@ -517,15 +614,19 @@ bool buildDeviceTableHIP(struct engineS *engine) {
 }
 
 bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *future) {
-    struct hipTable *t = table_from_rows(NULL, future, engine->all_records, (size_t)engine->num_records);
+    struct hipTable *t = calloc(1, sizeof *t);
+    if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+    table_fill(t, NULL, 0, future, engine->all_records, (size_t)engine->num_records);
     free(future);
     t->row_block = engine->record_block;               /* block handed over by getAllRecordsFromFileHIP */
-    t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 1);
+    t->row_capacity = (size_t)(engine->num_records > 0 ? engine->num_records : 0);
     if (t->row_block && engine->all_records) {                     /* what the two allocations really hold */
         const size_t cap_block = malloc_usable_size(t->row_block) / sizeof(record);
         const size_t cap_rows = malloc_usable_size(engine->all_records) / sizeof(record *);
         const size_t cap = cap_block < cap_rows ? cap_block : cap_rows;
         if (cap > t->row_capacity) t->row_capacity = cap;
+    } else {
+        t->row_capacity = 0;                                       /* no block yet: the first INSERT allocates one */
     }
     t->locks = calloc(1, sizeof *t->locks);
     if (!t->locks || pthread_rwlock_init(&t->locks->rows, NULL) != 0 || pthread_mutex_init(&t->locks->device, NULL) != 0) {
@@ -536,27 +637,31 @@ bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *futu
     return true;
 }
 
-/* Re-creates columns, dictionaries and indexes from the host rows (after INSERT / DELETE). */
+/* Re-creates columns, dictionaries and indexes from the host rows (after INSERT / DELETE), on the same
+ * contexts, re-balanced over the shards. */
 void rebuildDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = engine->record_block;          /* stays at this address: callers hold its locks */
-    pqps_ctx *ctx = t->ctx;
+    pqps_ctx *ctxs[HIP_MAX_SHARDS];
+    const int n_shards = hipTableShards(t);
+    for (int s = 0; s < n_shards; s++) ctxs[s] = hipTableShard(t, s)->ctx;
     record *block = t->row_block;
     const size_t row_capacity = t->row_capacity;
     struct hipLocks *locks = t->locks;
     table_release(t, engine->num_indexes);
-    struct hipTable *fresh = hipTableFromRows(ctx, engine->all_records, (size_t)engine->num_records);
-    *t = *fresh;
-    free(fresh);
+    memset(t, 0, sizeof *t);
+    table_fill(t, ctxs, n_shards, NULL, engine->all_records, (size_t)engine->num_records);
     t->row_block = block;
     t->row_capacity = row_capacity;
     t->locks = locks;
-    if (engine->num_indexes > 0) {
-        t->index = calloc((size_t)engine->num_indexes, sizeof *t->index);
-        for (int i = 0; i < engine->num_indexes; i++) build_index(engine, t, i);
+    for (int s = 0; s < n_shards && engine->num_indexes > 0; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        sh->index = calloc((size_t)engine->num_indexes, sizeof *sh->index);
+        if (!sh->index) { perror("Failed to allocate memory for engine components"); exit(EXIT_FAILURE); }
+        for (int i = 0; i < engine->num_indexes; i++) build_index(engine, sh, i);
     }
 }
 
-/* Rebuilds every device index (a device radix sort each; cheap next to a table rebuild). */
+/* Rebuilds every device index of one shard (a device radix sort each; cheap next to a table rebuild). */
 static void rebuild_indexes(struct engineS *engine, struct hipTable *t) {
     for (int i = 0; i < engine->num_indexes; i++) {
         if (t->index[i].perm_dev) pqps_free(t->ctx, t->index[i].perm_dev);
@@ -565,15 +670,17 @@ static void rebuild_indexes(struct engineS *engine, struct hipTable *t) {
     }
 }
 
-/* INSERT: appends the last host row (engine->all_records[n-1]) to the device columns in place.
- * A string value that is new to its dictionary is inserted at its rank and the codes at or
- * above that rank are bumped on the device (order-preserving codes stay order-preserving).
+/* INSERT: appends the last host row (engine->all_records[n-1]) to the device columns of the last shard
+ * in place.  A string value that is new to its dictionary is inserted at its rank and the codes at or
+ * above that rank are bumped on every shard (order-preserving codes stay order-preserving).
  * Falls back to a full rebuild only when a column has to change its code width or the
  * head-room is used up. */
 void appendRowDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = engine->record_block;
+    const int n_shards = hipTableShards(t);
+    struct hipTable *last = hipTableShard(t, n_shards - 1);
     const size_t n = (size_t)engine->num_records;               /* rows after the insert */
-    if (n == 0 || n - 1 != t->n_rows || n > t->capacity_rows) { rebuildDeviceTableHIP(engine); return; }
+    if (n == 0 || n - 1 != last->row0 + last->n_rows || last->n_rows + 1 > last->capacity_rows) { rebuildDeviceTableHIP(engine); return; }
     const record *r = engine->all_records[n - 1];
     /* first pass: would any dictionary outgrow its code width? */
     int pos[HIPCOL_COUNT], present[HIPCOL_COUNT];
@@ -588,6 +695,7 @@ void appendRowDeviceTableHIP(struct engineS *engine) {
         const uint64_t limit = t->col[c].width == 1 ? 256 : t->col[c].width == 2 ? 65536 : 0xFFFFFFFFull;
         if (!present[c] && (uint64_t)d->count + 1 > limit) { rebuildDeviceTableHIP(engine); return; }
     }
+    bool bumped = false;
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         const uint32_t w = t->col[c].width;
         uint64_t value = 0;
@@ -606,37 +714,52 @@ void appendRowDeviceTableHIP(struct engineS *engine) {
                 memmove(&d->values[pos[c] + 1], &d->values[pos[c]], ((size_t)d->count - (size_t)pos[c]) * sizeof *grown);
                 d->values[pos[c]] = copy;
                 d->count++;
-                if (pqps_bump_codes(t->ctx, (void *)t->col[c].data, w, t->n_rows, (uint32_t)pos[c], NULL) != PQPS_OK)
-                    hip_die("dictionary code shift");
+                for (int s = 0; s < n_shards; s++) {
+                    struct hipTable *sh = hipTableShard(t, s);
+                    if (pqps_bump_codes(sh->ctx, (void *)sh->col[c].data, w, sh->n_rows, (uint32_t)pos[c], NULL) != PQPS_OK)
+                        hip_die("dictionary code shift");
+                }
+                bumped = true;
             }
             value = (uint64_t)pos[c];
             break;
         }
         }
-        if (pqps_upload(t->ctx, (char *)t->col[c].data + (n - 1) * w, &value, w, NULL) != PQPS_OK) hip_die("row upload");
+        if (pqps_upload(last->ctx, (char *)last->col[c].data + last->n_rows * w, &value, w, NULL) != PQPS_OK) hip_die("row upload");
     }
-    t->n_rows = n;
-    rebuild_indexes(engine, t);
+    last->n_rows += 1;
+    for (int s = 0; s < n_shards; s++)                          /* shifted codes are keys of the other shards' indexes too */
+        if (bumped || s == n_shards - 1) rebuild_indexes(engine, hipTableShard(t, s));
 }
 
-/* DELETE: drops the flagged rows from the device columns in place and re-sorts the indexes. */
-void compactDeviceTableHIP(struct engineS *engine, const uint8_t *delete_flags_dev, size_t expected_rows) {
+/* DELETE: drops the flagged rows from the device columns of every shard in place and re-sorts the
+ * indexes; the shards keep their (now shorter) contiguous row ranges. */
+void compactDeviceTableHIP(struct engineS *engine, uint8_t *const *delete_flags_dev, size_t expected_rows) {
     struct hipTable *t = engine->record_block;
-    uint64_t kept = 0;
-    if (pqps_compact_rows(t->ctx, t->col, HIPCOL_COUNT, t->n_rows, delete_flags_dev, &kept, NULL) != PQPS_OK)
-        hip_die("row compaction");
-    if (kept != (uint64_t)expected_rows) {
-        fprintf(stderr, "HIP engine: device kept %llu rows, host kept %zu\n", (unsigned long long)kept, expected_rows);
+    uint64_t total = 0;
+    for (int s = 0; s < hipTableShards(t); s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        uint64_t kept = 0;
+        if (pqps_compact_rows(sh->ctx, sh->col, HIPCOL_COUNT, sh->n_rows, delete_flags_dev[s], &kept, NULL) != PQPS_OK)
+            hip_die("row compaction");
+        const bool changed = kept != sh->n_rows || sh->row0 != total;
+        sh->n_rows = kept;
+        sh->row0 = total;
+        total += kept;
+        if (changed) rebuild_indexes(engine, sh);
+    }
+    if (total != (uint64_t)expected_rows) {
+        fprintf(stderr, "HIP engine: device kept %llu rows, host kept %zu\n", (unsigned long long)total, expected_rows);
         exit(EXIT_FAILURE);
     }
-    t->n_rows = kept;
-    rebuild_indexes(engine, t);
 }
 
 void destroyDeviceTableHIP(struct engineS *engine) {
     struct hipTable *t = engine->record_block;
     if (!t) return;
-    pqps_ctx *ctx = t->ctx;
+    pqps_ctx *ctxs[HIP_MAX_SHARDS];
+    const int n_shards = hipTableShards(t);
+    for (int s = 0; s < n_shards; s++) ctxs[s] = hipTableShard(t, s)->ctx;
     const char *trace = getenv("PQPS_TRACE");
     struct timespec t0, t1, t2, t3;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -644,12 +767,12 @@ void destroyDeviceTableHIP(struct engineS *engine) {
     clock_gettime(CLOCK_MONOTONIC, &t1);
     hipTableFree(t, engine->num_indexes);
     clock_gettime(CLOCK_MONOTONIC, &t2);
-    pqps_ctx_destroy(ctx);
+    for (int s = 0; s < n_shards; s++) pqps_ctx_destroy(ctxs[s]);
     clock_gettime(CLOCK_MONOTONIC, &t3);
     if (trace && atoi(trace))
-        fprintf(stderr, "[pqps] destroy: host rows %.3f ms, device table %.3f ms, context %.3f ms\n",
+        fprintf(stderr, "[pqps] destroy: host rows %.3f ms, device table %.3f ms, %d context(s) %.3f ms\n",
                 (double)(t1.tv_sec - t0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-6,
-                (double)(t2.tv_sec - t1.tv_sec) * 1e3 + (double)(t2.tv_nsec - t1.tv_nsec) * 1e-6,
+                (double)(t2.tv_sec - t1.tv_sec) * 1e3 + (double)(t2.tv_nsec - t1.tv_nsec) * 1e-6, n_shards,
                 (double)(t3.tv_sec - t2.tv_sec) * 1e3 + (double)(t3.tv_nsec - t2.tv_nsec) * 1e-6);
     engine->record_block = NULL;
 }

@@ -36,39 +36,84 @@ static int trace_on(void) {
 }
 #define TRACE(...) do { if (trace_on()) fprintf(stderr, "[pqps] " __VA_ARGS__); } while (0)
 
-static void engine_die(const char *what) {
+/* A device call failed inside a query: the reason goes to stderr (like every diagnostic of the reference's
+ * engines) and the query reports failure to its caller -- the process, and the engine, carry on. */
+static int engine_error(const char *what) {
     fprintf(stderr, "HIP engine: %s: %s\n", what, pqps_last_error());
-    exit(EXIT_FAILURE);
+    return -1;
 }
 
-#define SHIM(call, what) do { if ((call) != PQPS_OK) engine_die(what); } while (0)
+#define TRY(call, what) do { if ((call) != PQPS_OK) return engine_error(what); } while (0)
 
 /* ---- predicate binding --------------------------------------------------------- */
 
-struct bound_pred {
-    pqps_predicate pred;
-    pqps_column cols[PQPS_MAX_COLUMNS];
-    uint32_t n_cols;
-};
-
-static void bind_where(const struct hipTable *t, const struct whereClauseS *where, struct bound_pred *bp) {
+/* The compiled WHERE of one query: usually one pass; see hipCompileWherePlan. */
+static int bind_where(const struct hipTable *t, const struct whereClauseS *where, struct hipPlan *plan) {
     struct hipSchema schema;
-    int col_ids[PQPS_MAX_COLUMNS];
     char err[160];
     hipSchemaOfTable(t, &schema);
-    if (hipCompileWhere(&schema, where, &bp->pred, col_ids, err, sizeof err) != 0) {
+    if (hipCompileWherePlan(&schema, where, plan, err, sizeof err) != 0) {
         fprintf(stderr, "HIP engine: cannot compile WHERE clause: %s\n", err);
-        exit(EXIT_FAILURE);
+        return -1;
     }
-    bp->n_cols = bp->pred.n_columns;
-    for (uint32_t i = 0; i < bp->n_cols; i++) bp->cols[i] = t->col[col_ids[i]];
+    return 0;
 }
 
-static void ensure_id_capacity(struct hipTable *t, uint64_t need) {
-    if (need <= t->capacity_ids) return;
+/* One shard's side of a plan: the flag buffers of the passes before the last, and the last pass's columns. */
+struct shard_pred {
+    const pqps_predicate *pred;
+    pqps_column cols[PQPS_MAX_COLUMNS];
+    uint32_t n_cols;
+    uint8_t **flags;                 /* n_passes - 1 device buffers (NULL for a single pass) */
+    int n_flags;
+};
+
+static void shard_pred_free(struct hipTable *sh, struct shard_pred *sp) {
+    for (int k = 0; k < sp->n_flags; k++) if (sp->flags[k]) pqps_free(sh->ctx, sp->flags[k]);
+    free(sp->flags);
+    sp->flags = NULL;
+    sp->n_flags = 0;
+}
+
+static void pass_columns(const struct hipTable *sh, const struct hipPass *pass, uint8_t *const *flags, pqps_column *cols) {
+    for (uint32_t i = 0; i < pass->pred.n_columns; i++) {
+        const int id = pass->column_ids[i];
+        if (id >= PQPS_MAX_COLUMNS) { cols[i].data = flags[id - PQPS_MAX_COLUMNS]; cols[i].width = 1; }
+        else cols[i] = sh->col[id];
+    }
+}
+
+/* Enqueues the passes before the last on the shard's stream (each one byte of flags per row) and binds the last. */
+static int shard_pred_prepare(struct hipTable *sh, const struct hipPlan *plan, struct shard_pred *sp) {
+    memset(sp, 0, sizeof *sp);
+    const struct hipPass *last = &plan->pass[plan->n_passes - 1];
+    if (plan->n_passes > 1) {
+        sp->flags = calloc((size_t)plan->n_passes - 1, sizeof *sp->flags);
+        if (!sp->flags) { fprintf(stderr, "HIP engine: out of memory\n"); return -1; }
+        sp->n_flags = plan->n_passes - 1;
+        for (int k = 0; k < sp->n_flags; k++) {
+            pqps_column cols[PQPS_MAX_COLUMNS];
+            TRY(pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&sp->flags[k]), "flag allocation");
+            pass_columns(sh, &plan->pass[k], sp->flags, cols);
+            TRY(pqps_filter_flags(sh->ctx, cols, plan->pass[k].pred.n_columns, sh->n_rows, &plan->pass[k].pred,
+                                  sp->flags[k], sh->count_dev + 4, NULL), "flag filter");
+        }
+    }
+    sp->pred = &last->pred;
+    sp->n_cols = last->pred.n_columns;
+    pass_columns(sh, last, sp->flags, sp->cols);
+    return 0;
+}
+
+static int ensure_id_capacity(struct hipTable *t, uint64_t need) {
+    if (need <= t->capacity_ids) return 0;
     pqps_free(t->ctx, t->ids_dev);
-    t->capacity_ids = need + need / 8 + 1024;
-    SHIM(pqps_malloc(t->ctx, t->capacity_ids * sizeof(uint32_t), (void **)&t->ids_dev), "result allocation");
+    t->ids_dev = NULL;
+    t->capacity_ids = 0;
+    const uint64_t cap = need + need / 8 + 1024;
+    TRY(pqps_malloc(t->ctx, cap * sizeof(uint32_t), (void **)&t->ids_dev), "result allocation");
+    t->capacity_ids = cap;
+    return 0;
 }
 
 /* Inclusive key window of an indexed top-level condition, S:377-424.
@@ -95,64 +140,184 @@ static void key_window_i32(const char *op, const char *value, uint64_t *lo, uint
     *hi = (uint64_t)(uint32_t)h;
 }
 
-/* Row selection of executeQuerySelectSerial, S:358-474, on the device.
- * Returns the number of result rows; the IDs are left in t->ids_dev. */
-static uint64_t run_selection(struct engineS *engine, struct hipTable *t, struct whereClauseS *where) {
-    struct bound_pred bp;
-    bind_where(t, where, &bp);
-    uint64_t *count_dev = t->count_dev, *range_dev = t->count_dev + 2;
+/* One index probe the serial engine would make for this WHERE (S:358-433), in its order. */
+struct probe { int index; uint64_t lo, hi; };
 
-    for (;;) {
-        bool any_index = false;
-        for (struct whereClauseS *wc = where; wc; wc = wc->next) {
-            if (wc->attribute == NULL) continue;                       /* nested node, S:361-364 */
-            for (int i = 0; i < engine->num_indexes; i++) {
-                if (strcmp(wc->attribute, engine->indexed_attributes[i]) != 0) continue;
-                const struct hipIndex *ix = &t->index[i];
-                if (ix->column < 0 || wc->operator == NULL || wc->value == NULL) continue;
-                uint64_t lo, hi;
-                /* only u64 / int indexes are probed by the serial engine, S:377-433 */
-                if (engine->attribute_types[i] == FIELD_UINT64 && t->col[ix->column].width == 8 && ix->key_kind == 0)
-                    key_window_u64(wc->operator, wc->value, &lo, &hi);
-                else if (engine->attribute_types[i] == FIELD_INT && ix->key_kind == 1)
-                    key_window_i32(wc->operator, wc->value, &lo, &hi);
-                else
-                    continue;
-                if (!any_index) SHIM(pqps_memset(t->ctx, count_dev, 0, sizeof(uint64_t), NULL), "counter reset");
-                any_index = true;
-                SHIM(pqps_index_probe(t->ctx, ix->keys_dev, t->col[ix->column].width, ix->key_kind,
-                                      t->n_rows, lo, hi, range_dev, NULL), "index probe");
-                /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
-                SHIM(pqps_filter_gather(t->ctx, bp.cols, bp.n_cols, ix->perm_dev, range_dev, t->n_rows, 0,
-                                        &bp.pred, t->ids_dev, t->capacity_ids, count_dev, NULL), "index filter");
+static int list_probes(struct engineS *engine, const struct hipTable *t, struct whereClauseS *where, struct probe **out) {
+    int n = 0, cap = 0;
+    struct probe *pr = NULL;
+    for (struct whereClauseS *wc = where; wc; wc = wc->next) {
+        if (wc->attribute == NULL) continue;                           /* nested node, S:361-364 */
+        for (int i = 0; i < engine->num_indexes; i++) {
+            if (strcmp(wc->attribute, engine->indexed_attributes[i]) != 0) continue;
+            const struct hipIndex *ix = &t->index[i];
+            if (ix->column < 0 || wc->operator == NULL || wc->value == NULL) continue;
+            uint64_t lo, hi;
+            /* only u64 / int indexes are probed by the serial engine, S:377-433 */
+            if (engine->attribute_types[i] == FIELD_UINT64 && t->col[ix->column].width == 8 && ix->key_kind == 0)
+                key_window_u64(wc->operator, wc->value, &lo, &hi);
+            else if (engine->attribute_types[i] == FIELD_INT && ix->key_kind == 1)
+                key_window_i32(wc->operator, wc->value, &lo, &hi);
+            else
+                continue;
+            if (n == cap) {
+                cap = cap ? 2 * cap : 8;
+                struct probe *grown = realloc(pr, (size_t)cap * sizeof *grown);
+                if (!grown) { free(pr); return -1; }
+                pr = grown;
             }
+            pr[n++] = (struct probe){ i, lo, hi };
         }
-        if (!any_index)                                                /* full scan, S:464-467 */
-            SHIM(pqps_filter_scan(t->ctx, bp.cols, bp.n_cols, t->n_rows, 0, &bp.pred,
-                                  t->ids_dev, t->capacity_ids, count_dev, NULL), "scan filter");
-        SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
-        uint64_t count = 0;
-        SHIM(pqps_download(t->ctx, &count, count_dev, sizeof count, NULL), "count download");
-        if (count <= t->capacity_ids) return count;
-        ensure_id_capacity(t, count);                                  /* duplicates can exceed n rows: retry larger */
     }
+    *out = pr;
+    return n;
 }
 
-/* Caller holds the rows lock (shared).  The device phase -- the context's scratch and the table's
- * result buffer serve one query at a time -- runs under the device lock. */
+/* Result of one row selection.  Scan mode: shard s holds count[s] ascending engine row numbers in its ids_dev;
+ * the answer is their concatenation in shard order.  Index mode: per probe, each shard appended its rows in
+ * (key asc, row desc) order; on one shard that is the answer as it stands, on several `merged` holds it. */
+struct selection {
+    uint64_t total;
+    uint64_t count[HIP_MAX_SHARDS];
+    unsigned int *merged;            /* host, `total` entries; index mode over several shards only */
+};
+
+static uint64_t row_key(const record *r, const FieldInfo *fi) {
+    const char *p = (const char *)r + fi->offset;
+    return fi->type == FIELD_UINT64 ? *(const uint64_t *)p : (uint64_t)((int64_t)*(const int *)p + 0x80000000ll);
+}
+
+/* Row selection of executeQuerySelectSerial, S:358-474, on the device(s). */
+static int run_selection(struct engineS *engine, struct hipTable *t, struct whereClauseS *where, struct selection *sel) {
+    memset(sel, 0, sizeof *sel);
+    const int n_shards = hipTableShards(t);
+    struct hipPlan plan;
+    if (bind_where(t, where, &plan) != 0) return -1;
+    struct probe *probes = NULL;
+    const int n_probes = list_probes(engine, t, where, &probes);
+    struct shard_pred sp[HIP_MAX_SHARDS];
+    memset(sp, 0, sizeof sp);
+    uint64_t *seg_end = NULL;                                          /* [probe][shard] running counts */
+    int rc = n_probes < 0 ? -1 : 0;
+#define RUN(call, what) do { if (rc == 0 && (call) != PQPS_OK) rc = engine_error(what); } while (0)
+    for (int s = 0; s < n_shards && rc == 0; s++) rc = shard_pred_prepare(hipTableShard(t, s), &plan, &sp[s]);
+    if (rc == 0 && n_probes > 0 && n_shards > 1) {
+        seg_end = malloc((size_t)n_probes * (size_t)n_shards * sizeof *seg_end);
+        if (!seg_end) rc = -1;
+    }
+    for (bool again = true; rc == 0 && again; ) {
+        again = false;
+        if (n_probes > 0) {
+            for (int s = 0; s < n_shards; s++) {
+                struct hipTable *sh = hipTableShard(t, s);
+                RUN(pqps_memset(sh->ctx, sh->count_dev, 0, sizeof(uint64_t), NULL), "counter reset");
+            }
+            for (int k = 0; k < n_probes && rc == 0; k++) {
+                for (int s = 0; s < n_shards; s++) {
+                    struct hipTable *sh = hipTableShard(t, s);
+                    const struct hipIndex *ix = &sh->index[probes[k].index];
+                    uint64_t *range_dev = sh->count_dev + 2;
+                    RUN(pqps_index_probe(sh->ctx, ix->keys_dev, sh->col[ix->column].width, ix->key_kind,
+                                         sh->n_rows, probes[k].lo, probes[k].hi, range_dev, NULL), "index probe");
+                    /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
+                    RUN(pqps_filter_gather(sh->ctx, sp[s].cols, sp[s].n_cols, ix->perm_dev, range_dev, sh->n_rows,
+                                           (uint32_t)sh->row0, sp[s].pred, sh->ids_dev, sh->capacity_ids, sh->count_dev, NULL), "index filter");
+                }
+                if (seg_end)                                           /* where this probe's rows end on every shard */
+                    for (int s = 0; s < n_shards; s++) {
+                        struct hipTable *sh = hipTableShard(t, s);
+                        RUN(pqps_download(sh->ctx, &seg_end[(size_t)k * (size_t)n_shards + (size_t)s], sh->count_dev, sizeof(uint64_t), NULL), "count download");
+                    }
+            }
+        } else {                                                       /* full scan, S:464-467: all shards at once */
+            for (int s = 0; s < n_shards; s++) {
+                struct hipTable *sh = hipTableShard(t, s);
+                RUN(pqps_filter_scan(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, (uint32_t)sh->row0, sp[s].pred,
+                                     sh->ids_dev, sh->capacity_ids, sh->count_dev, NULL), "scan filter");
+            }
+        }
+        sel->total = 0;
+        for (int s = 0; s < n_shards; s++) {
+            struct hipTable *sh = hipTableShard(t, s);
+            RUN(pqps_ctx_sync(sh->ctx, NULL), "filter execution");
+            RUN(pqps_download(sh->ctx, &sel->count[s], sh->count_dev, sizeof(uint64_t), NULL), "count download");
+            if (rc == 0 && sel->count[s] > sh->capacity_ids) {         /* duplicates can exceed n rows: retry larger */
+                rc = ensure_id_capacity(sh, sel->count[s]);
+                again = true;
+            }
+            sel->total += sel->count[s];
+        }
+    }
+    if (rc == 0 && seg_end && sel->total > 0) {
+        /* several shards, index mode: every probe's segment is sorted by (key asc, row desc) on each shard, and
+         * the shards hold ascending row ranges -- merge the segments probe by probe */
+        unsigned int *part[HIP_MAX_SHARDS];
+        memset(part, 0, sizeof part);
+        sel->merged = malloc(sel->total * sizeof *sel->merged);
+        if (!sel->merged) rc = -1;
+        for (int s = 0; s < n_shards && rc == 0; s++) {
+            struct hipTable *sh = hipTableShard(t, s);
+            part[s] = malloc((sel->count[s] ? sel->count[s] : 1) * sizeof **part);
+            if (!part[s]) { rc = -1; break; }
+            if (sel->count[s]) RUN(pqps_download(sh->ctx, part[s], sh->ids_dev, sel->count[s] * sizeof **part, NULL), "ID download");
+        }
+        uint64_t w = 0, at[HIP_MAX_SHARDS];
+        memset(at, 0, sizeof at);
+        for (int k = 0; k < n_probes && rc == 0; k++) {
+            const FieldInfo *fi = get_field_info(engine->indexed_attributes[probes[k].index]);
+            const uint64_t *end = &seg_end[(size_t)k * (size_t)n_shards];
+            for (;;) {
+                int best = -1;
+                uint64_t best_key = 0;
+                for (int s = n_shards - 1; s >= 0; s--) {             /* ties: the higher rows (later shard) first */
+                    if (at[s] >= end[s]) continue;
+                    const uint64_t key = row_key(engine->all_records[part[s][at[s]]], fi);
+                    if (best < 0 || key < best_key) { best = s; best_key = key; }
+                }
+                if (best < 0) break;
+                sel->merged[w++] = part[best][at[best]++];
+            }
+        }
+        for (int s = 0; s < n_shards; s++) free(part[s]);
+    }
+#undef RUN
+    for (int s = 0; s < n_shards; s++) shard_pred_free(hipTableShard(t, s), &sp[s]);
+    free(seg_end);
+    free(probes);
+    hipPlanFree(&plan);
+    if (rc != 0) { free(sel->merged); sel->merged = NULL; }
+    return rc;
+}
+
+/* Caller holds the rows lock (shared).  The device phase -- the contexts' scratch and the shards'
+ * result buffers serve one query at a time -- runs under the device lock. */
 static long long select_ids(struct engineS *engine, struct whereClauseS *whereClause,
                             unsigned int **ids, double *queryTime) {
     struct hipTable *t = engine->record_block;
     const double t0 = now_seconds();
+    struct selection sel;
+    *ids = NULL;
     hipTableLockDevice(t);
-    const uint64_t count = run_selection(engine, t, whereClause);
-    unsigned int *out = malloc((count ? count : 1) * sizeof *out);
-    if (!out) { perror("Failed to allocate memory for result IDs"); exit(EXIT_FAILURE); }
-    if (count) SHIM(pqps_download(t->ctx, out, t->ids_dev, count * sizeof *out, NULL), "ID download");
+    int rc = run_selection(engine, t, whereClause, &sel);
+    unsigned int *out = NULL;
+    if (rc == 0 && sel.merged) {
+        out = sel.merged;
+    } else if (rc == 0) {
+        out = malloc((sel.total ? sel.total : 1) * sizeof *out);
+        if (!out) { fprintf(stderr, "HIP engine: out of memory for %llu result IDs\n", (unsigned long long)sel.total); rc = -1; }
+        uint64_t at = 0;
+        for (int s = 0; s < hipTableShards(t) && rc == 0; s++) {
+            struct hipTable *sh = hipTableShard(t, s);
+            if (sel.count[s] && pqps_download(sh->ctx, out + at, sh->ids_dev, sel.count[s] * sizeof *out, NULL) != PQPS_OK)
+                rc = engine_error("ID download");
+            at += sel.count[s];
+        }
+        if (rc != 0) { free(out); out = NULL; }
+    }
     hipTableUnlockDevice(t);
     if (queryTime) *queryTime = now_seconds() - t0;
     *ids = out;
-    return (long long)count;
+    return rc == 0 ? (long long)sel.total : -1;
 }
 
 long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
@@ -164,20 +329,42 @@ long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *
     return count;
 }
 
+static int count_rows(struct hipTable *t, struct whereClauseS *whereClause, uint64_t *total) {
+    struct hipPlan plan;
+    if (bind_where(t, whereClause, &plan) != 0) return -1;
+    const int n_shards = hipTableShards(t);
+    struct shard_pred sp[HIP_MAX_SHARDS];
+    memset(sp, 0, sizeof sp);
+    int rc = 0;
+    *total = 0;
+    for (int s = 0; s < n_shards && rc == 0; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        rc = shard_pred_prepare(sh, &plan, &sp[s]);
+        if (rc == 0 && pqps_filter_count(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, sp[s].pred, sh->count_dev, NULL) != PQPS_OK)
+            rc = engine_error("count filter");
+    }
+    for (int s = 0; s < n_shards; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        uint64_t count = 0;
+        if (rc == 0 && pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) rc = engine_error("filter execution");
+        if (rc == 0 && pqps_download(sh->ctx, &count, sh->count_dev, sizeof count, NULL) != PQPS_OK) rc = engine_error("count download");
+        *total += count;
+        shard_pred_free(sh, &sp[s]);
+    }
+    hipPlanFree(&plan);
+    return rc;
+}
+
 long long executeQueryCountHIP(struct engineS *engine, struct whereClauseS *whereClause) {
     if (!engine || !engine->record_block) return -1;
     struct hipTable *t = engine->record_block;
+    uint64_t total = 0;
     hipTableLockShared(t);
-    struct bound_pred bp;
-    bind_where(t, whereClause, &bp);
     hipTableLockDevice(t);
-    SHIM(pqps_filter_count(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, t->count_dev, NULL), "count filter");
-    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
-    uint64_t count = 0;
-    SHIM(pqps_download(t->ctx, &count, t->count_dev, sizeof count, NULL), "count download");
+    const int rc = count_rows(t, whereClause, &total);
     hipTableUnlockDevice(t);
     hipTableUnlock(t);
-    return (long long)count;
+    return rc == 0 ? (long long)total : -1;
 }
 
 /* ---- projection ------------------------------------------------------------------ */
@@ -231,6 +418,11 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
     if (!engine || !engine->record_block) { rs->success = false; return rs; }
     hipTableLockShared(engine->record_block);          /* the projection below reads the host rows */
     const long long count = select_ids(engine, whereClause, &ids, &qtime);
+    if (count < 0) {                                   /* reason already on stderr */
+        hipTableUnlock(engine->record_block);
+        rs->success = false;
+        return rs;
+    }
 
     rs->numRecords = (int)count;
     if (selectItems == NULL || numSelectItems == 0) {  /* SELECT *, S:490-492 */
@@ -276,6 +468,124 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
 
 /* ---- columnar SELECT ------------------------------------------------------------------------------- */
 
+/* Dictionary codes of a result column become self-contained: the codes are widened to u32 and re-numbered
+ * 0..k-1 over the k distinct values the result holds (still ascending in strcmp order), and the result owns a
+ * copy of those k strings -- it stays valid whatever INSERT / DELETE / destroy later do to the engine. */
+static int own_dictionary(struct hipColumnarResult *res, int j, const struct hipDictionary *d, uint32_t w, uint64_t count) {
+    void *raw = res->values[j];
+    uint32_t *wide = w == 4 ? raw : malloc(count * sizeof *wide);
+    uint32_t *local = calloc((size_t)(d->count > 0 ? d->count : 1), sizeof *local);
+    if (!wide || !local) { if (wide != raw) free(wide); free(local); fprintf(stderr, "HIP engine: out of memory for the result set\n"); return -1; }
+    if (w == 1) for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint8_t *)raw)[i];
+    else if (w == 2) for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint16_t *)raw)[i];
+    if (wide != raw) { free(raw); res->values[j] = wide; }
+    for (uint64_t i = 0; i < count; i++) local[wide[i]] = 1;
+    int k = 0;
+    for (int v = 0; v < d->count; v++) if (local[v]) k++;
+    char **values = malloc((size_t)(k ? k : 1) * sizeof *values);
+    if (!values) { free(local); fprintf(stderr, "HIP engine: out of memory for the result set\n"); return -1; }
+    k = 0;
+    for (int v = 0; v < d->count; v++) {
+        if (!local[v]) continue;
+        values[k] = strdup(d->values[v]);
+        local[v] = (uint32_t)k++;
+    }
+    for (uint64_t i = 0; i < count; i++) wide[i] = local[wide[i]];
+    free(local);
+    res->dictionaries[j] = (const char *const *)values;
+    res->dictionarySizes[j] = k;
+    return 0;
+}
+
+/* Device gather of one column for the selected rows of every shard, into `raw` (result order). */
+static int project_column(struct hipTable *t, const struct selection *sel, int c, void *const *gathered,
+                          unsigned int *const *sub_pos, char *raw, char *tmp) {
+    const uint32_t w = t->col[c].width;
+    uint64_t at = 0;
+    for (int s = 0; s < hipTableShards(t); s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        const uint64_t k = sel->count[s];
+        if (k == 0) continue;
+        TRY(pqps_project_column(sh->ctx, &sh->col[c], sh->ids_dev, sh->count_dev, k, (uint32_t)sh->row0, gathered[s], NULL), "device projection");
+        if (!sel->merged) {
+            TRY(pqps_download(sh->ctx, raw + at * w, gathered[s], k * w, NULL), "projection download");
+        } else {                                                        /* rows of this shard are scattered over the merged order */
+            TRY(pqps_download(sh->ctx, tmp, gathered[s], k * w, NULL), "projection download");
+            for (uint64_t i = 0; i < k; i++) memcpy(raw + (size_t)sub_pos[s][i] * w, tmp + i * w, w);
+        }
+        at += k;
+    }
+    return 0;
+}
+
+static int select_columnar(struct engineS *engine, struct hipTable *t, const char **selectItems, int numSelectItems,
+                           struct whereClauseS *whereClause, struct hipColumnarResult *res) {
+    struct selection sel;
+    if (run_selection(engine, t, whereClause, &sel) != 0) return -1;    /* IDs stay in the shards' ids_dev, the counts in count_dev */
+    const int n_shards = hipTableShards(t);
+    const uint64_t count = sel.total;
+    struct hipSchema schema;
+    hipSchemaOfTable(t, &schema);
+    void *gathered[HIP_MAX_SHARDS];
+    unsigned int *sub_pos[HIP_MAX_SHARDS];
+    memset(gathered, 0, sizeof gathered);
+    memset(sub_pos, 0, sizeof sub_pos);
+    char *tmp = NULL;
+    int rc = 0;
+    if (sel.merged) {
+        /* index mode over several shards: each shard gathers for its own rows in merged order (its sub-list
+         * replaces the shard-order list on the device), the values are scattered to their merged positions */
+        uint64_t fill[HIP_MAX_SHARDS], biggest = 0;
+        memset(fill, 0, sizeof fill);
+        unsigned int *sub_ids[HIP_MAX_SHARDS];
+        memset(sub_ids, 0, sizeof sub_ids);
+        for (int s = 0; s < n_shards; s++) {
+            sub_ids[s] = malloc((sel.count[s] ? sel.count[s] : 1) * sizeof **sub_ids);
+            sub_pos[s] = malloc((sel.count[s] ? sel.count[s] : 1) * sizeof **sub_pos);
+            if (!sub_ids[s] || !sub_pos[s]) rc = -1;
+            if (sel.count[s] > biggest) biggest = sel.count[s];
+        }
+        for (uint64_t i = 0; i < count && rc == 0; i++) {
+            const unsigned int id = sel.merged[i];
+            int s = n_shards - 1;
+            while (s > 0 && id < hipTableShard(t, s)->row0) s--;
+            sub_ids[s][fill[s]] = id;
+            sub_pos[s][fill[s]++] = (unsigned int)i;
+        }
+        for (int s = 0; s < n_shards && rc == 0; s++) {
+            struct hipTable *sh = hipTableShard(t, s);
+            if (sel.count[s] && pqps_upload(sh->ctx, sh->ids_dev, sub_ids[s], sel.count[s] * sizeof **sub_ids, NULL) != PQPS_OK)
+                rc = engine_error("ID upload");
+        }
+        for (int s = 0; s < n_shards; s++) free(sub_ids[s]);
+        tmp = malloc((biggest ? biggest : 1) * 8);
+        if (!tmp) rc = -1;
+    }
+    for (int s = 0; s < n_shards && rc == 0; s++)
+        if (sel.count[s] && pqps_malloc(hipTableShard(t, s)->ctx, sel.count[s] * 8, &gathered[s]) != PQPS_OK) rc = engine_error("projection buffer");
+    for (int j = 0; j < numSelectItems && rc == 0; j++) {
+        res->columnNames[j] = strdup(selectItems[j]);
+        const int c = hipColumnId(selectItems[j]);
+        res->columnKinds[j] = c < 0 ? -1 : schema.col[c].kind;
+        if (c < 0 || count == 0) continue;
+        const uint32_t w = t->col[c].width;
+        char *raw = malloc(count * w);
+        if (!raw) { fprintf(stderr, "HIP engine: out of memory for the result set\n"); rc = -1; break; }
+        res->values[j] = raw;
+        rc = project_column(t, &sel, c, gathered, sub_pos, raw, tmp);
+        if (rc == 0 && schema.col[c].kind == HIPKIND_DICT)
+            rc = own_dictionary(res, j, &t->dict[c], w, count);
+    }
+    for (int s = 0; s < n_shards; s++) {
+        if (gathered[s]) pqps_free(hipTableShard(t, s)->ctx, gathered[s]);
+        free(sub_pos[s]);
+    }
+    free(tmp);
+    free(sel.merged);
+    res->numRecords = (int)count;
+    return rc;
+}
+
 struct hipColumnarResult *executeQuerySelectColumnarHIP(struct engineS *engine, const char **selectItems, int numSelectItems,
                                                         struct whereClauseS *whereClause) {
     struct hipColumnarResult *res = calloc(1, sizeof *res);
@@ -288,45 +598,18 @@ struct hipColumnarResult *executeQuerySelectColumnarHIP(struct engineS *engine, 
     res->columnKinds = calloc((size_t)numSelectItems, sizeof(int));
     res->values = calloc((size_t)numSelectItems, sizeof(void *));
     res->dictionaries = calloc((size_t)numSelectItems, sizeof(*res->dictionaries));
-    if (!res->columnNames || !res->columnKinds || !res->values || !res->dictionaries) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+    res->dictionarySizes = calloc((size_t)numSelectItems, sizeof(int));
+    if (!res->columnNames || !res->columnKinds || !res->values || !res->dictionaries || !res->dictionarySizes) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
 
     const double t0 = now_seconds();
     hipTableLockShared(t);
     hipTableLockDevice(t);
-    const uint64_t count = run_selection(engine, t, whereClause);      /* IDs stay in t->ids_dev, the count in t->count_dev */
-    struct hipSchema schema;
-    hipSchemaOfTable(t, &schema);
-    void *gathered = NULL;
-    if (count) SHIM(pqps_malloc(t->ctx, count * 8, &gathered), "projection buffer");
-    for (int j = 0; j < numSelectItems; j++) {
-        res->columnNames[j] = strdup(selectItems[j]);
-        const int c = hipColumnId(selectItems[j]);
-        res->columnKinds[j] = c < 0 ? -1 : schema.col[c].kind;
-        if (c < 0 || count == 0) continue;
-        const uint32_t w = t->col[c].width;
-        SHIM(pqps_project_column(t->ctx, &t->col[c], t->ids_dev, t->count_dev, count, 0, gathered, NULL), "device projection");
-        void *raw = malloc(count * w);
-        if (!raw) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
-        SHIM(pqps_download(t->ctx, raw, gathered, count * w, NULL), "projection download");
-        if (schema.col[c].kind == HIPKIND_DICT) {                       /* codes are widened to u32 whatever the column stores */
-            res->dictionaries[j] = schema.col[c].dict;
-            if (w != 4) {
-                uint32_t *wide = malloc(count * sizeof *wide);
-                if (!wide) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
-                if (w == 1) for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint8_t *)raw)[i];
-                else for (uint64_t i = 0; i < count; i++) wide[i] = ((const uint16_t *)raw)[i];
-                free(raw);
-                raw = wide;
-            }
-        }
-        res->values[j] = raw;
-    }
-    if (gathered) pqps_free(t->ctx, gathered);
+    const int rc = select_columnar(engine, t, selectItems, numSelectItems, whereClause, res);
     hipTableUnlockDevice(t);
     hipTableUnlock(t);
-    res->numRecords = (int)count;
     res->queryTime = now_seconds() - t0;
-    res->success = true;
+    res->success = rc == 0;
+    if (rc != 0) res->numRecords = 0;
     TRACE("SELECT (columnar): %d rows x %d columns in %.3f ms\n", res->numRecords, res->numColumns, res->queryTime * 1e3);
     return res;
 }
@@ -336,8 +619,12 @@ void freeColumnarResultHIP(struct hipColumnarResult *res) {
     for (int j = 0; j < res->numColumns; j++) {
         if (res->columnNames) free(res->columnNames[j]);
         if (res->values) free(res->values[j]);
+        if (res->dictionaries && res->dictionaries[j]) {
+            for (int v = 0; v < res->dictionarySizes[j]; v++) free((void *)res->dictionaries[j][v]);
+            free((void *)res->dictionaries[j]);
+        }
     }
-    free(res->columnNames); free(res->columnKinds); free(res->values); free((void *)res->dictionaries);
+    free(res->columnNames); free(res->columnKinds); free(res->values); free((void *)res->dictionaries); free(res->dictionarySizes);
     free(res);
 }
 
@@ -418,34 +705,43 @@ static pqps_ctx *adhoc_ctx(void) {
         int device = 0;
         const char *env = getenv("PQPS_DEVICE");
         if (env) device = atoi(env);
-        SHIM(pqps_ctx_create(device, &g_adhoc_ctx), "cannot create a device context");
+        if (pqps_ctx_create(device, &g_adhoc_ctx) != PQPS_OK) { engine_error("cannot create a device context"); g_adhoc_ctx = NULL; }
     }
     return g_adhoc_ctx;
 }
 
+static int adhoc_search(struct hipTable *t, record **records, struct whereClauseS *whereClause, record ***out, int *matching) {
+    struct selection sel;
+    struct engineS none;                                /* no indexes: always the scan path */
+    memset(&none, 0, sizeof none);
+    if (run_selection(&none, t, whereClause, &sel) != 0) return -1;
+    const uint64_t count = sel.total;
+    uint32_t *ids = malloc((count ? count : 1) * sizeof *ids);
+    record **hit = malloc((count ? count : 1) * sizeof *hit);
+    if (!ids || !hit) { free(ids); free(hit); fprintf(stderr, "HIP engine: out of memory for results\n"); return -1; }
+    if (count && pqps_download(t->ctx, ids, t->ids_dev, count * sizeof *ids, NULL) != PQPS_OK) { free(ids); free(hit); return engine_error("ID download"); }
+    for (uint64_t i = 0; i < count; i++) hit[i] = records[ids[i]];
+    free(ids);
+    *out = hit;
+    *matching = (int)count;
+    return 0;
+}
+
 /* linearSearchRecords, S:854-878: the rows are columnarised, filtered on the
- * GPU (input order kept) and the surviving pointers returned. */
+ * GPU (input order kept) and the surviving pointers returned.  NULL (and 0 matches) when the device or
+ * the clause fails; the reason is on stderr. */
 record **linearSearchRecords(record **records, int num_records, struct whereClauseS *whereClause,
                              int *matchingRecords) {
     *matchingRecords = 0;
+    record **out = NULL;
     pthread_mutex_lock(&g_adhoc_lock);
-    struct hipTable *t = hipTableFromRows(adhoc_ctx(), records, (size_t)(num_records > 0 ? num_records : 0));
-    struct bound_pred bp;
-    bind_where(t, whereClause, &bp);
-    SHIM(pqps_filter_scan(t->ctx, bp.cols, bp.n_cols, t->n_rows, 0, &bp.pred,
-                          t->ids_dev, t->capacity_ids, t->count_dev, NULL), "scan filter");
-    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
-    uint64_t count = 0;
-    SHIM(pqps_download(t->ctx, &count, t->count_dev, sizeof count, NULL), "count download");
-    uint32_t *ids = malloc((count ? count : 1) * sizeof *ids);
-    record **out = malloc((count ? count : 1) * sizeof *out);
-    if (!ids || !out) { perror("Failed to allocate memory for results"); exit(EXIT_FAILURE); }
-    if (count) SHIM(pqps_download(t->ctx, ids, t->ids_dev, count * sizeof *ids, NULL), "ID download");
-    for (uint64_t i = 0; i < count; i++) out[i] = records[ids[i]];
-    free(ids);
-    hipTableFree(t, 0);
+    pqps_ctx *ctx = adhoc_ctx();
+    if (ctx) {
+        struct hipTable *t = hipTableFromRows(ctx, records, (size_t)(num_records > 0 ? num_records : 0));
+        if (adhoc_search(t, records, whereClause, &out, matchingRecords) != 0) { out = NULL; *matchingRecords = 0; }
+        hipTableFree(t, 0);
+    }
     pthread_mutex_unlock(&g_adhoc_lock);
-    *matchingRecords = (int)count;
     return out;
 }
 
@@ -509,6 +805,16 @@ bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const c
     const bool ok = makeIndexHIP(engine, attributeName, attributeType);
     hipTableUnlock(engine->record_block);
     return ok;
+}
+
+int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity) {
+    if (!engine || !engine->record_block) return 0;
+    struct hipTable *t = engine->record_block;
+    hipTableLockShared(t);
+    const int n = hipTableShards(t);
+    for (int s = 0; rows && s < n && s < capacity; s++) rows[s] = hipTableShard(t, s)->n_rows;
+    hipTableUnlock(t);
+    return n;
 }
 
 /* ---- mutation (kept in step with the CSV like the reference) ------------------------------ */
@@ -608,23 +914,26 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     struct hipTable *t = engine->record_block;
     const double t0 = now_seconds();
     hipTableLockExclusive(t);
+    const size_t n = (size_t)engine->num_records;
+    /* room for the row first: a failed allocation must not leave the CSV one row ahead of the engine.
+     * The host row store grows geometrically; all_records[] is re-pointed only when the block moved */
+    if (n + 1 > t->row_capacity) {
+        const size_t cap = n + n / 8 + 64;
+        record *block = realloc(t->row_block, cap * sizeof *block);
+        if (block) {
+            if (block != t->row_block) for (size_t i = 0; i < n; i++) engine->all_records[i] = &block[i];
+            t->row_block = block;
+        }
+        record **rows = block ? realloc(engine->all_records, cap * sizeof *rows) : NULL;
+        if (rows) engine->all_records = rows;
+        if (!block || !rows) { hipTableUnlock(t); return false; }
+        t->row_capacity = cap;
+    }
     FILE *f = fopen(engine->datafile, "a");
     if (!f) { hipTableUnlock(t); return false; }
     write_csv_row(f, r);
     fclose(f);
 
-    const size_t n = (size_t)engine->num_records;
-    /* host row store grows geometrically; all_records[] is re-pointed only when the block moved */
-    if (n + 1 > t->row_capacity) {
-        const size_t cap = n + n / 8 + 64;
-        record *block = realloc(t->row_block, cap * sizeof *block);
-        record **rows = realloc(engine->all_records, cap * sizeof *rows);
-        if (!block || !rows) { hipTableUnlock(t); return false; }
-        if (block != t->row_block) for (size_t i = 0; i < n; i++) rows[i] = &block[i];
-        t->row_block = block;
-        t->row_capacity = cap;
-        engine->all_records = rows;
-    }
     t->row_block[n] = *r;
     engine->all_records[n] = &t->row_block[n];
     engine->num_records = (int)(n + 1);
@@ -637,6 +946,32 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
 
 /* executeQueryDeleteSerial, S:627-715: the per-row decision is the GPU flag
  * kernel (the flag-array shape of engine/omp/executeEngine-omp.c:708-732). */
+/* Flags of the rows that go, per shard on the device and for the whole table on the host. */
+static int delete_flags(struct hipTable *t, struct whereClauseS *whereClause, size_t n, uint8_t **flags_dev, uint8_t *flags) {
+    struct hipPlan plan;
+    if (bind_where(t, whereClause, &plan) != 0) return -1;
+    const int n_shards = hipTableShards(t);
+    struct shard_pred sp[HIP_MAX_SHARDS];
+    memset(sp, 0, sizeof sp);
+    int rc = 0;
+    for (int s = 0; s < n_shards && rc == 0; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        rc = shard_pred_prepare(sh, &plan, &sp[s]);
+        if (rc == 0 && pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&flags_dev[s]) != PQPS_OK) rc = engine_error("flag allocation");
+        if (rc == 0 && pqps_filter_flags(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, sp[s].pred, flags_dev[s], sh->count_dev, NULL) != PQPS_OK)
+            rc = engine_error("flag filter");
+    }
+    for (int s = 0; s < n_shards; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        if (rc == 0 && pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) rc = engine_error("filter execution");
+        if (rc == 0 && sh->row0 + sh->n_rows > n) { fprintf(stderr, "HIP engine: device shards hold more rows than the host\n"); rc = -1; }
+        if (rc == 0 && sh->n_rows && pqps_download(sh->ctx, flags + sh->row0, flags_dev[s], sh->n_rows, NULL) != PQPS_OK) rc = engine_error("flag download");
+        shard_pred_free(sh, &sp[s]);
+    }
+    hipPlanFree(&plan);
+    return rc;
+}
+
 struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tableName,
                                          struct whereClauseS *whereClause) {
     (void)tableName;
@@ -646,13 +981,18 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     struct hipTable *t = engine->record_block;
     hipTableLockExclusive(t);
     const size_t n = (size_t)engine->num_records;
-    struct bound_pred bp;
-    bind_where(t, whereClause, &bp);
-    uint8_t *flags_dev = NULL, *flags = malloc(t->capacity_rows);
-    SHIM(pqps_malloc(t->ctx, t->capacity_rows, (void **)&flags_dev), "flag allocation");
-    SHIM(pqps_filter_flags(t->ctx, bp.cols, bp.n_cols, t->n_rows, &bp.pred, flags_dev, t->count_dev, NULL), "flag filter");
-    SHIM(pqps_ctx_sync(t->ctx, NULL), "filter execution");
-    if (n) SHIM(pqps_download(t->ctx, flags, flags_dev, n, NULL), "flag download");
+    const int n_shards = hipTableShards(t);
+    uint8_t *flags_dev[HIP_MAX_SHARDS];
+    memset(flags_dev, 0, sizeof flags_dev);
+    uint8_t *flags = malloc(n ? n : 1);
+    if (!flags || delete_flags(t, whereClause, n, flags_dev, flags) != 0) {
+        if (!flags) fprintf(stderr, "HIP engine: out of memory for %zu delete flags\n", n);
+        for (int s = 0; s < n_shards; s++) if (flags_dev[s]) pqps_free(hipTableShard(t, s)->ctx, flags_dev[s]);
+        free(flags);
+        hipTableUnlock(t);
+        rs->success = false;                                       /* nothing was deleted */
+        return rs;
+    }
     const double t1 = now_seconds();
 
     size_t keep = 0, deleted = 0;
@@ -673,10 +1013,10 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
         fclose(f);
     }
     const double t3 = now_seconds();
-    /* device side: the same flags compact the 12 columns in place (order kept); dictionaries
+    /* device side: the same flags compact the 12 columns of every shard in place (order kept); dictionaries
      * stay as they are (a code without rows is harmless), indexes are re-sorted */
     if (deleted) compactDeviceTableHIP(engine, flags_dev, keep);
-    pqps_free(t->ctx, flags_dev);
+    for (int s = 0; s < n_shards; s++) pqps_free(hipTableShard(t, s)->ctx, flags_dev[s]);
     TRACE("DELETE: %zu of %zu rows, flags %.3f ms, host rows %.3f ms, CSV rewrite %.3f ms, device compaction + indexes %.3f ms\n",
           deleted, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now_seconds() - t3) * 1e3);
     hipTableUnlock(t);

@@ -105,6 +105,20 @@ static void window_dict(struct step *s, int op, const char *lit, const struct hi
     }
 }
 
+/* Result flags of an earlier pass of a multi-pass plan, bound like a 1-byte column: its column id is
+ * PQPS_MAX_COLUMNS + pass number, its leaf is `flags = 1`.  The planner names it "\x01<pass>". */
+#define FLAG_ATTRIBUTE '\x01'
+static const struct hipColumnInfo k_flag_column = { 1, HIPKIND_BOOL, 1, 0, NULL };
+
+static const struct hipColumnInfo *col_info(const struct hipSchema *schema, int col) {
+    return col >= PQPS_MAX_COLUMNS ? &k_flag_column : &schema->col[col];
+}
+
+static int attribute_column(const char *attribute) {
+    if (attribute && attribute[0] == FLAG_ATTRIBUTE) return PQPS_MAX_COLUMNS + atoi(attribute + 1);
+    return hipColumnId(attribute);
+}
+
 struct builder {
     const struct hipSchema *schema;
     struct step st[MAX_RAW_STEPS];
@@ -124,11 +138,12 @@ static int count_leaves(const struct whereClauseS *wc) {
 static void make_leaf(struct builder *b, struct step *s, const struct whereClauseS *c) {
     s->kind = ST_FALSE;
     s->col = -1;
-    const int col = hipColumnId(c->attribute);
+    const int col = attribute_column(c->attribute);
     const int op = op_code(c->operator);
     if (col < 0 || op < 0 || c->value == NULL) return;          /* S:212, S:279: never true */
-    const struct hipColumnInfo *ci = &b->schema->col[col];
+    const struct hipColumnInfo *ci = col_info(b->schema, col);
     s->col = col;
+    if (col >= PQPS_MAX_COLUMNS) { s->kind = ST_LEAF; s->lo = 1; s->span = 0; s->neg = 0; return; }
     /* the literal is typed by the column, not by the token (S:256-276) */
     if (strcmp(c->attribute, "command_id") == 0) {
         window_unsigned(s, op, strtoull(c->value, NULL, 10), UINT64_MAX);
@@ -221,7 +236,7 @@ int hipCompileWhere(const struct hipSchema *schema, const struct whereClauseS *w
     /* only leaves that can actually be evaluated may name an absent column */
     int absent = 0;
     for (int s = 0; s < raw; s++)
-        if (reach[s] && !schema->col[b->st[s].col].present) absent = 1;
+        if (reach[s] && !col_info(schema, b->st[s].col)->present) absent = 1;
     if (b->failed && !absent) { b->failed = 0; if (err && errlen) err[0] = '\0'; }
     if (b->failed) { free(b); return -1; }
 
@@ -242,11 +257,19 @@ int hipCompileWhere(const struct hipSchema *schema, const struct whereClauseS *w
     for (int s = 0; s < raw; s++) if (reach[s]) cols[nc++] = b->st[s].col;
     qsort(cols, (size_t)nc, sizeof cols[0], cmp_int);
     int n_cols = 0;
-    for (int i = 0; i < nc; i++) if (i == 0 || cols[i] != cols[i - 1]) column_ids[n_cols++] = cols[i];
+    for (int i = 0; i < nc; i++) {
+        if (i != 0 && cols[i] == cols[i - 1]) continue;
+        if (n_cols == PQPS_MAX_COLUMNS) {
+            if (err) snprintf(err, errlen, "WHERE reads more than %d columns in one pass", PQPS_MAX_COLUMNS);
+            free(b);
+            return -1;
+        }
+        column_ids[n_cols++] = cols[i];
+    }
     for (int i = 1; i < n_cols; i++) {                           /* stable insertion sort by width desc */
         const int c = column_ids[i];
         int j = i;
-        while (j > 0 && schema->col[column_ids[j - 1]].width < schema->col[c].width) { column_ids[j] = column_ids[j - 1]; j--; }
+        while (j > 0 && col_info(schema, column_ids[j - 1])->width < col_info(schema, c)->width) { column_ids[j] = column_ids[j - 1]; j--; }
         column_ids[j] = c;
     }
 
@@ -292,4 +315,143 @@ int hipCompileWhere(const struct hipSchema *schema, const struct whereClauseS *w
     }
     free(b);
     return 0;
+}
+
+/* ---- multi-pass plans ----------------------------------------------------------------------------- */
+
+struct planner {
+    const struct hipSchema *schema;
+    struct hipPlan *plan;
+    int capacity;
+    void **arena; int n_arena, cap_arena;
+    char *err; size_t errlen;
+};
+
+static void *plan_alloc(struct planner *P, size_t bytes) {
+    if (P->n_arena == P->cap_arena) {
+        const int cap = P->cap_arena ? 2 * P->cap_arena : 16;
+        void **grown = realloc(P->arena, (size_t)cap * sizeof *grown);
+        if (!grown) return NULL;
+        P->arena = grown; P->cap_arena = cap;
+    }
+    void *p = calloc(1, bytes ? bytes : 1);
+    if (p) P->arena[P->n_arena++] = p;
+    return p;
+}
+
+/* distinct columns a chain would bind: table columns once each, every flag column */
+static void chain_columns(const struct whereClauseS *wc, uint32_t *table_mask, int *flag_columns) {
+    for (; wc; wc = wc->next) {
+        if (wc->sub) { chain_columns(wc->sub, table_mask, flag_columns); continue; }
+        const int col = attribute_column(wc->attribute);
+        if (col >= PQPS_MAX_COLUMNS) *flag_columns += 1;
+        else if (col >= 0) *table_mask |= 1u << col;
+    }
+}
+
+static int element_leaves(const struct whereClauseS *e) { return e->sub ? count_leaves(e->sub) : 1; }
+
+/* does [first, last] (elements of one array) fit one pass? */
+static int span_fits(const struct whereClauseS *first, const struct whereClauseS *last) {
+    int leaves = 0, flags = 0;
+    uint32_t mask = 0;
+    for (const struct whereClauseS *e = first; e <= last; e++) {
+        leaves += element_leaves(e);
+        if (e->sub) chain_columns(e->sub, &mask, &flags);
+        else {
+            const int col = attribute_column(e->attribute);
+            if (col >= PQPS_MAX_COLUMNS) flags++; else if (col >= 0) mask |= 1u << col;
+        }
+    }
+    return leaves <= PQPS_MAX_LEAVES && __builtin_popcount(mask) + flags <= PQPS_MAX_COLUMNS;
+}
+
+/* Compiles `chain` as the next pass; returns its number, -1 on failure. */
+static int emit_pass(struct planner *P, const struct whereClauseS *chain) {
+    struct hipPlan *plan = P->plan;
+    if (plan->n_passes == P->capacity) {
+        const int cap = P->capacity ? 2 * P->capacity : 4;
+        struct hipPass *grown = realloc(plan->pass, (size_t)cap * sizeof *grown);
+        if (!grown) { if (P->err) snprintf(P->err, P->errlen, "out of memory"); return -1; }
+        plan->pass = grown; P->capacity = cap;
+    }
+    struct hipPass *pass = &plan->pass[plan->n_passes];
+    if (hipCompileWhere(P->schema, chain, &pass->pred, pass->column_ids, P->err, P->errlen) != 0) return -1;
+    return plan->n_passes++;
+}
+
+static int make_flag_leaf(struct planner *P, struct whereClauseS *e, int pass) {
+    char *name = plan_alloc(P, 16);
+    if (!name) { if (P->err) snprintf(P->err, P->errlen, "out of memory"); return -1; }
+    snprintf(name, 16, "%c%d", FLAG_ATTRIBUTE, pass);
+    e->attribute = name;
+    e->operator = "=";
+    e->value = "1";
+    e->sub = NULL;
+    return 0;
+}
+
+/* A chain equivalent to `chain` that fits one pass; what does not fit is evaluated by earlier passes and
+ * read back as flag leaves.  evaluateWhereClause (S:292-316) is right-recursive: `e AND rest` / `e OR rest`
+ * only ever continue at the START of rest, so any suffix of the element list can be evaluated first and
+ * replaced by one leaf; a parenthesised element is a value of its own and can be replaced likewise. */
+static struct whereClauseS *fit_chain(struct planner *P, const struct whereClauseS *chain) {
+    int n = 0;
+    for (const struct whereClauseS *wc = chain; wc; wc = wc->next) n++;
+    struct whereClauseS *el = plan_alloc(P, (size_t)n * sizeof *el);
+    if (!el) { if (P->err) snprintf(P->err, P->errlen, "out of memory"); return NULL; }
+    int i = 0;
+    for (const struct whereClauseS *wc = chain; wc; wc = wc->next, i++) {
+        el[i] = *wc;
+        el[i].next = i + 1 < n ? &el[i + 1] : NULL;
+    }
+    for (i = 0; i < n; i++) {
+        if (!el[i].sub || (span_fits(&el[i], &el[i]) && count_leaves(el[i].sub) < PQPS_MAX_LEAVES)) continue;
+        struct whereClauseS *inner = fit_chain(P, el[i].sub);        /* too large for one pass even alone */
+        const int pass = inner ? emit_pass(P, inner) : -1;
+        if (pass < 0 || make_flag_leaf(P, &el[i], pass) != 0) return NULL;
+    }
+    while (!span_fits(&el[0], &el[n - 1])) {
+        int first = n - 1;                                            /* longest suffix that fits a pass */
+        while (first > 0 && span_fits(&el[first - 1], &el[n - 1])) first--;
+        if (first == n - 1 && element_leaves(&el[n - 1]) == 1) {
+            /* a lone leaf: replacing it gains nothing.  The element before it (a parenthesised one, or the
+             * two would fit together) becomes a leaf first. */
+            if (n < 2 || !el[n - 2].sub) { if (P->err) snprintf(P->err, P->errlen, "WHERE cannot be split into passes"); return NULL; }
+            const int pass = emit_pass(P, el[n - 2].sub);
+            if (pass < 0 || make_flag_leaf(P, &el[n - 2], pass) != 0) return NULL;
+            continue;
+        }
+        const int pass = emit_pass(P, &el[first]);
+        if (pass < 0 || make_flag_leaf(P, &el[first], pass) != 0) return NULL;
+        el[first].next = NULL;
+        el[first].logical_op = NULL;
+        n = first + 1;
+    }
+    return el;
+}
+
+int hipCompileWherePlan(const struct hipSchema *schema, const struct whereClauseS *where,
+                        struct hipPlan *plan, char *err, size_t errlen) {
+    memset(plan, 0, sizeof *plan);
+    struct planner P;
+    memset(&P, 0, sizeof P);
+    P.schema = schema; P.plan = plan; P.err = err; P.errlen = errlen;
+    /* one pass whenever the clause allows it (constant leaves are folded away first) */
+    if (count_leaves(where) <= MAX_RAW_STEPS && emit_pass(&P, where) == 0) return 0;
+    if (err && errlen) err[0] = '\0';
+    plan->n_passes = 0;
+    struct whereClauseS *fitted = fit_chain(&P, where);
+    const int last = fitted ? emit_pass(&P, fitted) : -1;
+    for (int i = 0; i < P.n_arena; i++) free(P.arena[i]);
+    free(P.arena);
+    if (last < 0) { hipPlanFree(plan); return -1; }
+    return 0;
+}
+
+void hipPlanFree(struct hipPlan *plan) {
+    if (!plan) return;
+    free(plan->pass);
+    plan->pass = NULL;
+    plan->n_passes = 0;
 }

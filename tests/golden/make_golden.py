@@ -423,6 +423,120 @@ def random_goldens(csv2k, n_cases=220, seed=20260101):
     print(f"random select cases: {len(out)} pinned ({nonempty} with matches), {dropped} dropped (candidate overflow)")
 
 
+def wide_where_cases(csv2k, seed=20260202):
+    """WHERE lists with more than 32 comparisons (the device predicate's size: the HIP engine splits them into
+    passes).  The reference's PARSER takes at most 5 conditions per level, its engine API any list -- these are
+    built as whereClauseS lists, below the parser.  Literals from the table, like random_where_cases."""
+    import csv as csvmod
+    import random
+    rng = random.Random(seed)
+    with open(csv2k, newline="", encoding="latin-1") as f:
+        rows = list(csvmod.DictReader(f))
+    numeric = ["command_id", "exit_code", "user_id", "risk_level"]
+    strings = ["raw_command", "base_command", "shell_type", "timestamp", "working_directory", "user_name", "host_name"]
+    every = numeric + strings + ["sudo_used"]
+    pool = {c: sorted({r[c] for r in rows}) for c in strings}
+    pool.update({c: sorted({r[c] for r in rows}, key=int) for c in numeric})
+    ops = ["=", "!=", "<", "<=", ">", ">="]
+
+    def condition(columns=None):
+        c = rng.choice(columns or every)
+        if c in numeric:
+            return (c, rng.choice(ops), rng.choice(pool[c]), 0)
+        if c in strings:
+            return (c, rng.choice(ops), rng.choice(pool[c]), 1)
+        return ("sudo_used", rng.choice(["=", "!="]), rng.choice(["TRUE", "FALSE"]), 1)
+
+    def join(parts, glue=None):
+        out = []
+        for i, part in enumerate(parts):
+            out.append(part)
+            if i + 1 < len(parts):
+                out.append(glue or rng.choice(["AND", "OR"]))
+        return out
+
+    def flat(k, columns=None, glue=None):
+        return join([condition(columns) for _ in range(k)], glue)
+
+    def window():
+        v = int(rng.choice(pool["command_id"]))
+        return [("command_id", ">=", str(v), 0), "AND", ("command_id", "<=", str(v + rng.randrange(0, 40)), 0)]
+
+    cases = []
+    for i in range(3):       # a: one flat list of 40 / 47 / 70 conditions, no parentheses at all
+        cases.append((f"Wa{i}", ["command_id", "risk_level"], flat([40, 47, 70][i])))
+    for i in range(2):       # b: 5 x (5 x pair) = 50 leaves
+        cases.append((f"Wb{i}", ["command_id"], join([join([flat(2) for _ in range(5)]) for _ in range(5)])))
+    for i in range(2):       # c: one parenthesised element of 45 leaves (too large even alone) between plain conditions
+        big = join([join([flat(3) for _ in range(3)]) for _ in range(5)])
+        cases.append((f"Wc{i}", None, join([condition(), big, condition(), condition()])))
+    for i in range(2):       # d: all 12 columns inside each of 5 elements (the 12-column budget of a pass), 60 leaves
+        def twelve():
+            cols = every[:]
+            rng.shuffle(cols)
+            return join([join([condition([c]) for c in cols[k:k + 3]]) for k in range(0, 12, 3)])
+        cases.append((f"Wd{i}", ["command_id"], join([twelve() for _ in range(5)], "OR")))
+    for i in range(2):       # e: OR of 36 narrow command_id windows (72 leaves on one column, few rows)
+        cases.append((f"We{i}", ["command_id", "user_name"], join([window() for _ in range(36)], "OR")))
+    # f: 4 levels deep, 5 x 5 x 2 x 2 = 100 leaves
+    cases.append(("Wf0", ["command_id"], join([join([join([flat(2) for _ in range(2)]) for _ in range(5)]) for _ in range(5)])))
+    # g: 33 leaves exactly -- a 31-leaf parenthesised element, then two conditions
+    cases.append(("Wg0", ["command_id"], [flat(31), "AND", condition(), "OR", condition()]))
+    # h: a long AND list that narrows to few rows, then an OR tail
+    loose = join([(c, "!=", rng.choice(pool[c]), 0) for c in rng.choices(["exit_code", "user_id", "command_id"], k=34)], "AND")
+    cases.append(("Wh0", None, loose + ["AND", ("risk_level", ">", "3", 0), "OR"] + window()))
+    return cases
+
+
+def count_chain_leaves(chain):
+    return sum(count_chain_leaves(e) if isinstance(e, list) else 1 for e in chain[0::2])
+
+
+def render_chain(chain):
+    out = []
+    for i, e in enumerate(chain):
+        if i % 2 == 1:
+            out.append(e)
+        elif isinstance(e, list):
+            out.append("(" + render_chain(e) + ")")
+        else:
+            out.append(f'{e[0]} {e[1]} "{e[2]}"' if e[3] else f"{e[0]} {e[1]} {e[2]}")
+    return " ".join(out)
+
+
+def wide_goldens(csv2k):
+    """select_wide_golden.json: the > 32-comparison lists through the REAL reference's engine API
+    (executeQuerySelectSerial on the whereClauseS list: oracle/ref_harness.c refh_select_where), scan mode and
+    the default five indexes; same record layout as select_random_golden.json ("sql" is a rendering for the
+    reader: the reference's parser would drop conditions past the fifth of a level)."""
+    q.load_ref()
+    q.build_oracle()
+    out = []
+    engines = {cfg: q.RefEngine(csv2k, INDEX_CONFIGS[cfg]) for cfg in ("none", "default")}
+    oracles = {cfg: q.OracleTable(csv2k, INDEX_CONFIGS[cfg]) for cfg in ("none", "default")}
+    for name, cols, chain in wide_where_cases(csv2k):
+        leaves = count_chain_leaves(chain)
+        assert leaves > 32, (name, leaves)
+        for cfg in ("none", "default"):
+            eng, orc = engines[cfg], oracles[cfg]
+            o_ids, o_count, cand = orc.select_ids(chain)
+            if cand > eng.n:
+                print(f"{name}/{cfg}: candidate overflow in the reference, dropped")
+                continue
+            res = eng.select_where(cols, chain)
+            r2 = eng.select_where(["command_id"], chain)
+            ids = [int(r[0]) for r in r2["rows"]]
+            assert ids == o_ids, (name, cfg)
+            out.append({"name": name, "csv": csv2k.name, "indexes": cfg,
+                        "sql": compose(", ".join(cols) if cols else "*", render_chain(chain)), "where": q.chain_to_jsonable(chain),
+                        "leaves": leaves, "candidates": cand, "pinned": True, "num_records": res["numRecords"],
+                        "columns": res["columns"], "rows_sha256": sha_rows(res["rows"]), "ids_zlib_b64": q.pack_ids(ids)})
+            print(f"{name}/{cfg}: {leaves} leaves, {cand} candidates, {res['numRecords']} rows")
+    for e in engines.values():
+        e.close()
+    (HERE / "select_wide_golden.json").write_text(json.dumps(out, separators=(",", ":")))
+
+
 def driver_goldens(csv2k):
     """End-to-end driver goldens: the reference's QPESeq on its own sample-queries.txt and
     sample-queries-FULL.txt (which adds Sample 6, the DELETE).  The driver always opens
@@ -449,6 +563,8 @@ if __name__ == "__main__":
     import sys
     if "--driver-only" in sys.argv:
         driver_goldens(HERE / "commands_2k.csv")
+    elif "--wide-only" in sys.argv:
+        wide_goldens(HERE / "commands_2k.csv")
     elif "--random-only" in sys.argv:
         random_goldens(HERE / "commands_2k.csv")
     else:

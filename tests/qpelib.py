@@ -176,6 +176,9 @@ def load_ref():
         f.argtypes = [C.c_char_p, C.c_char_p, C.c_longlong]
     lib.refh_select.restype = C.c_longlong
     lib.refh_select.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_longlong]
+    if hasattr(lib, "refh_select_where"):
+        lib.refh_select_where.restype = C.c_longlong
+        lib.refh_select_where.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, W, C.c_char_p, C.c_longlong]
     lib.refh_print.restype = C.c_int
     lib.refh_print.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p]
     lib.refh_index_order.restype = C.c_int
@@ -229,7 +232,10 @@ class RefEngine:
         self.n = self.lib.refh_num_records(self.h)
 
     def select(self, sql):
-        text = call_text(self.lib.refh_select, self.h, sql.encode("latin-1"))
+        return self._result(call_text(self.lib.refh_select, self.h, sql.encode("latin-1")))
+
+    @staticmethod
+    def _result(text):
         if text is None:
             return None
         recs = text.split(RS)[:-1]
@@ -239,6 +245,13 @@ class RefEngine:
         assert int(head[0]) == len(rows)
         return dict(numRecords=int(head[0]), numColumns=int(head[1]), success=head[2] == "1",
                     columns=names, rows=rows)
+
+    def select_where(self, columns, chain):
+        """executeQuerySelectSerial on a chain built here (no parser: any number of conditions per level)."""
+        wl = WhereList(chain)
+        items = c_str_array(columns or [])
+        text = call_text(self.lib.refh_select_where, self.h, items, len(columns or []), wl.ptr)
+        return self._result(text)
 
     def record(self, i):
         r = Record()

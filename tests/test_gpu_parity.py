@@ -26,7 +26,8 @@ pq = q.pq
 pytestmark = pytest.mark.gpu
 
 SELECT = (json.loads((q.GOLDEN / "select_golden.json").read_text())
-          + json.loads((q.GOLDEN / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
+          + json.loads((q.GOLDEN / "select_random_golden.json").read_text())     # + seeded random WHERE trees, same reference
+          + json.loads((q.GOLDEN / "select_wide_golden.json").read_text()))       # + lists of more than 32 comparisons, reference engine API
 INDEX_CONFIGS = {
     "none": [],
     "default": pq.DEFAULT_INDEXES,

@@ -18,7 +18,8 @@ import qpelib as q
 
 GOLD = q.GOLDEN
 SELECT = (json.loads((GOLD / "select_golden.json").read_text())
-          + json.loads((GOLD / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
+          + json.loads((GOLD / "select_random_golden.json").read_text())     # + seeded random WHERE trees, same reference
+          + json.loads((GOLD / "select_wide_golden.json").read_text()))       # + lists of more than 32 comparisons, reference engine API
 INDEX_CONFIGS = {
     "none": [],
     "default": q.DEFAULT_INDEXES,

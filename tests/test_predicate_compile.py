@@ -14,7 +14,8 @@ import qpelib as q
 
 pq = q.pq
 SELECT = (json.loads((q.GOLDEN / "select_golden.json").read_text())
-          + json.loads((q.GOLDEN / "select_random_golden.json").read_text()))     # + seeded random WHERE trees, same reference
+          + json.loads((q.GOLDEN / "select_random_golden.json").read_text())      # + seeded random WHERE trees, same reference
+          + json.loads((q.GOLDEN / "select_wide_golden.json").read_text()))       # + lists of more than 32 comparisons (several passes)
 _cache = {}
 
 
@@ -27,10 +28,18 @@ def setup(csv):
 
 
 def model_ids(spec, arrays, chain):
-    pred, ids = pq.compile_where(spec, chain)
-    cols = [arrays[pq.COLUMNS[i]] for i in ids]
-    mask = km.evaluate(pred, cols)
+    """The compiled plan through the numpy model: passes before the last leave one flag byte per row."""
+    passes = pq.compile_plan(spec, chain)
     n = len(arrays["command_id"])
+    flags = []
+    for pred, ids in passes:
+        cols = [flags[i - pq.MAX_COLUMNS] if i >= pq.MAX_COLUMNS else arrays[pq.COLUMNS[i]] for i in ids]
+        assert len(cols) <= pq.MAX_COLUMNS and pred.n_leaves <= pq.MAX_LEAVES
+        mask = km.evaluate(pred, cols)
+        flags.append((np.ones(n, dtype=np.uint8) if mask else np.zeros(n, dtype=np.uint8)) if isinstance(mask, bool)
+                     else mask.astype(np.uint8))
+    if len(passes) == 1:
+        assert pq.compile_where(spec, chain)[1] == ids          # one pass: the plan is hipCompileWhere's own result
     if isinstance(mask, bool):
         return list(range(n)) if mask else [], pred
     return list(np.nonzero(mask)[0]), pred
@@ -91,13 +100,7 @@ def test_random_where_trees(seed):
     big = 0
     for _ in range(60):
         chain = random_chain(rng, depth=3, max_items=5)
-        if count_leaves(chain) > 40:
-            continue
-        try:
-            got, pred = model_ids(spec, arrays, chain)
-        except pq.PqpsError as e:
-            assert "limit" in str(e)
-            continue
+        got, pred = model_ids(spec, arrays, chain)               # any size: large trees become several passes
         big += pred.n_leaves > pq.TT_LEAVES
         want, _, _ = t.select_ids(chain)
         assert got == want, chain
@@ -112,6 +115,26 @@ def test_edge_csv_random_trees():
         got, _ = model_ids(spec, arrays, chain)
         want, _, _ = t.select_ids(chain)
         assert got == want, chain
+
+
+def test_wide_lists_become_several_passes():
+    t, spec, arrays = setup("commands_2k.csv")
+    wide = [c for c in SCAN_CASES if c.get("leaves", 0) > pq.MAX_LEAVES]
+    assert len(wide) >= 10
+    several = 0
+    for case in wide:
+        passes = pq.compile_plan(spec, q.chain_from_jsonable(case["where"]))
+        several += len(passes) > 1
+        for pred, ids in passes[:-1]:
+            assert pred.n_leaves <= pq.MAX_LEAVES and len(ids) <= pq.MAX_COLUMNS
+    assert several >= 8          # the rest fold down to one pass (constant leaves, unreachable branches)
+    # a clause of any size compiles: 600 conditions in one flat list
+    chain = []
+    for i in range(600):
+        chain += [("command_id", "=", str(3 * i + 1)), "OR"]
+    chain += [("risk_level", ">", "9")]
+    got, _ = model_ids(spec, arrays, chain)
+    assert got == t.select_ids(chain)[0] and len(got) > 100
 
 
 def test_constant_predicates_fold():
