@@ -242,7 +242,10 @@ def main():
         mm = torch.tensor([local_matches], dtype=torch.int64, device=cdev)
         dist.all_reduce(mm, op=dist.ReduceOp.MAX)
         max_matches = int(mm.item())
-    slot_cap = (int(max_matches * 1.25) + 4096) // 4096 * 4096 if not count_mode else 4096
+    # every rank's result buffer holds its whole shard: a result can never be too large for it (the gathered
+    # list on the other side of the exchange is sized from the counts, query by query)
+    slot_cap = (count + 4096) // 4096 * 4096 if (exchange and not count_mode) else \
+        ((int(max_matches * 1.25) + 4096) // 4096 * 4096 if not count_mode else 4096)
     del cal_ids
     native = exchange and args.exchange == "rccl" and args.backend == "nccl"
     # N = 1: a stream of queries -- the expanders behind the last scan tile of query k run on a second
@@ -254,21 +257,10 @@ def main():
     xch, mergers = None, None
     if native:
         # every rank must take the same path: if the shim-driven exchange cannot be set up on any of them
-        # (RCCL library not found, communicator refused), all fall back to the torch.distributed collectives
-        try:
-            xch = mg.ShardExchange(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING)
-            ok = 1
-        except Exception as e:                                   # noqa: BLE001
-            print(f"[bench] rank {rank}: shim-driven exchange unavailable ({e!r}); falling back to --exchange torch",
-                  file=sys.stderr, flush=True)
-            xch, ok = None, 0
-        agreed = torch.tensor([ok], dtype=torch.int64, device=cdev)
-        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) == 0:
-            if xch is not None:
-                xch.close()
-                xch = None
-            native = False
+        # (RCCL library not found, allocation failed, communicator refused), all fall back to the
+        # torch.distributed collectives -- the ranks agree before and after the communicator is built
+        xch = mg.ShardExchange.open(pq, ctx, torch, dist, world, rank, slot_cap, ring=RING, control_device=cdev)
+        native = xch is not None
     if not native:
         mergers = [mg.IdMerger(torch, dist, world, rank, slot_cap, device, ctx=ctx, pq=pq,
                                host_staged=(args.backend != "nccl"), always_collective=args.force_merge) for _ in range(RING)]
@@ -315,10 +307,30 @@ def main():
                     dist.all_reduce(t)
                     count_all[r] = t[0]
             else:
-                m.merge(stream_ptr=comm.cuda_stream)
+                # sizes of query k first, then the payload of query k-1: the host's wait for those sizes falls
+                # under this query's scan (same order as the shim-driven exchange)
+                m.begin(stream_ptr=comm.cuda_stream)
+                prev = mergers[(k - 1) % RING]
+                if prev is not m and prev._pending:
+                    prev.finish()
+                    merge_done[(k - 1) % RING].record(comm)
+                if RING == 1:
+                    m.finish()
             merge_done[r].record(comm)
 
+    def drain():
+        """Payload phases still held back (the last query's) go out."""
+        if xch is not None:
+            xch.sync()
+        elif exchange and not count_mode:
+            with torch.cuda.stream(comm):
+                for j in range(RING):
+                    if mergers[j]._pending:
+                        mergers[j].finish()
+                        merge_done[j].record(comm)
+
     def fence():
+        drain()
         torch.cuda.synchronize()
         if exchange:
             dist.barrier()

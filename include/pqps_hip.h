@@ -239,24 +239,40 @@ int pqps_qstream_sync(pqps_qstream *q);
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset);
 int pqps_qstream_destroy(pqps_qstream *q);
 
-/* ---- multi-GPU SELECT: shard scan + ONE RCCL all-gather + device merge, one host call per query ----
- * Replaces the exchange step of engine/mpi/executeEngine-mpi.c:717-768 (local scan of the rank's row
- * range, MPI_Allgather of the sizes, MPI_Allgatherv of the payload).  One process per GPU; every rank
- * makes the same calls in the same order.  RCCL is loaded at run time from `rccl_library` (e.g. the
- * librccl.so of the process's torch build, or /opt/rocm/lib/librccl.so); the 128-byte id is produced on
- * rank 0 and handed to the other ranks by whatever bootstrap the host has (torch.distributed broadcast,
- * MPI_Bcast, a file).
+/* ---- multi-GPU SELECT: shard scan + all-gatherv of the matching row IDs over RCCL, one host call per query ----
+ * Replaces the exchange step of engine/mpi/executeEngine-mpi.c:717-768 and keeps its shape: local scan of
+ * the rank's row range, MPI_Allgather of the sizes (:753), displacements = exclusive prefix (:758-762),
+ * MPI_Allgatherv of the payload (:765).  RCCL has no all-gatherv: the sizes travel in an 8-byte-per-rank
+ * ncclAllGather, the payload as ONE group of ncclSend / ncclRecv of exactly count[r] IDs between every pair of
+ * ranks, landing at its displacement -- nothing padded on the wire, no compaction pass, and no receive buffer
+ * that could be too small (the gathered list is grown to the sizes before the payload moves).
+ * One process per GPU; every rank makes the same calls in the same order.  RCCL is loaded at run time from
+ * `rccl_library` (e.g. the librccl.so of the process's torch build, or /opt/rocm/lib/librccl.so); the
+ * 128-byte id is produced on rank 0 and handed to the other ranks by whatever bootstrap the host has
+ * (torch.distributed broadcast, MPI_Bcast, a file).
+ *
+ * Bring-up in two steps so that a rank that fails locally cannot leave the others blocked:
+ *   pqps_exchange_prepare   everything local (library, stream, buffers, scratch contexts); no communication
+ *   (the host's bootstrap agrees that every rank prepared)
+ *   pqps_exchange_connect   ncclCommInitRank -- returns once every rank of the world has called it
+ * pqps_exchange_create = prepare + connect, for a host that has no such agreement step.
  *
  * pqps_exchange_select(x, ..., slot, scan_stream) enqueues, without blocking on the device:
- *   scan_stream     : the filter kernels, writing [count | IDs] into ring slot `slot`
- *   exchange stream : (behind an event) ncclAllGather of the slot, pqps_merge_slots
- * so query k's exchange runs under the scan of query k+1.  A slot may be reused after `ring` further
- * calls; reuse waits on the host for the earlier merge.  pqps_exchange_result() waits for a slot's
- * merge and returns the device pointer of the merged ascending ID list (identical on every rank),
- * totals[0] = IDs merged, totals[1] = IDs reported; PQPS_EOVERFLOW if a rank's slot was too small. */
+ *   scan_stream     : the filter launch, writing [count | IDs] into ring slot `slot` (`slot_capacity` IDs: give it
+ *                     the shard's row count and it can never be too small)
+ *   exchange stream : (behind an event) the all-gather of the sizes and their copy to the host
+ * and then finishes the queries handed in BEFORE this one: waits on the host for their sizes, enqueues their
+ * send / recv group.  So the host's wait for query k's sizes falls under the scan of query k+1, and the
+ * payload of query k moves under it too.  A slot may be reused after `ring` further calls; reuse waits on the
+ * host for the earlier exchange.  pqps_exchange_result() finishes the slot if need be, waits for it and returns
+ * the device pointer of the gathered ascending ID list (identical on every rank; valid until the slot is used
+ * again), totals[0] = IDs gathered, totals[1] = IDs reported; PQPS_EOVERFLOW if a rank's own slot was too small. */
 typedef struct { char internal[128]; } pqps_rccl_id;     /* = ncclUniqueId */
 typedef struct pqps_exchange pqps_exchange;
 int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id);
+int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t world, uint32_t rank,
+                          uint64_t slot_capacity, uint32_t ring, pqps_exchange **out);
+int pqps_exchange_connect(pqps_exchange *x, const pqps_rccl_id *id);
 int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world,
                          uint32_t rank, uint64_t slot_capacity, uint32_t ring, pqps_exchange **out);
 int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
@@ -268,8 +284,12 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
                         const pqps_predicate *pred, uint32_t slot, void *scan_stream);
 int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
                          uint64_t totals[2]);
+/* Finishes every query handed in so far (enqueues the payload groups still held back) and waits for the
+ * exchange stream: call it before stopping a clock or tearing down. */
 int pqps_exchange_sync(pqps_exchange *x);
-uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset);      /* as pqps_qstream_wait_ns */
+/* Host time (ns) spent waiting -- for a ring slot to come free or for the sizes of a query -- as opposed to
+ * time inside runtime / RCCL calls; `reset` != 0 clears the counter. */
+uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset);
 int pqps_exchange_destroy(pqps_exchange *x);
 
 /* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */

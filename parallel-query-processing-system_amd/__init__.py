@@ -267,6 +267,8 @@ def lib():
     L.pqps_qstream_destroy.argtypes = [vp]
     L.pqps_exchange_unique_id.argtypes = [C.c_char_p, vp]
     L.pqps_exchange_create.argtypes = [vp, C.c_char_p, vp, u32, u32, u64, u32, C.POINTER(vp)]
+    L.pqps_exchange_prepare.argtypes = [vp, C.c_char_p, u32, u32, u64, u32, C.POINTER(vp)]
+    L.pqps_exchange_connect.argtypes = [vp, vp]
     L.pqps_exchange_select.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), u32, vp]
     L.pqps_exchange_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), u32, vp]
     L.pqps_exchange_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]

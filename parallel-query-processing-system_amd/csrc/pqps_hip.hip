@@ -1225,12 +1225,16 @@ int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint6
     return PQPS_OK;
 }
 
-// ---- multi-GPU SELECT: shard scan + one RCCL all-gather + device merge -------------------------
-// The whole exchange step of engine/mpi/executeEngine-mpi.c:703-768 behind ONE host call per query:
-// scan kernels on the caller's stream, then -- on the exchange's own stream, behind an event -- the
-// all-gather of this rank's [count | IDs] slot and the compaction.  RCCL is resolved at run time from
-// the library the caller names (the process's torch build ships one; /opt/rocm/lib/librccl.so is the
-// system one), so the single-GPU engine does not link against it.
+// ---- multi-GPU SELECT: shard scan + all-gatherv of the matching row IDs over RCCL -----------------
+// The exchange step of engine/mpi/executeEngine-mpi.c:703-768 with its own shape kept: MPI_Allgather of the
+// per-rank sizes (:753), displacements = exclusive prefix (:758-762), MPI_Allgatherv of the payload (:765).
+// RCCL has no all-gatherv: the sizes travel in an 8-byte-per-rank ncclAllGather, the payload as one group of
+// ncclSend / ncclRecv of exactly count[r] IDs to / from every peer, landing at its displacement -- no
+// padding on the wire, no compaction pass, and no slot that could be too small.  The sizes have to reach the
+// host between the two (they are arguments of the send / recv calls); that round trip is hidden by finishing
+// query k's exchange only after query k+1's scan has been enqueued (see pqps_exchange_select).
+// RCCL is resolved at run time from the library the caller names (the process's torch build ships one;
+// /opt/rocm/lib/librccl.so is the system one), so the single-GPU engine does not link against it.
 }  // extern "C"
 
 namespace {
@@ -1241,11 +1245,15 @@ struct RcclApi {
     int (*CommInitRank)(void **comm, int nranks, pqps_rccl_id id, int rank);
     int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t s);
     int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s);
+    int (*Send)(const void *send, size_t count, int dtype, int peer, void *comm, hipStream_t s);
+    int (*Recv)(void *recv, size_t count, int dtype, int peer, void *comm, hipStream_t s);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
     int (*CommDestroy)(void *comm);
     const char *(*GetErrorString)(int rc);
 };
 
-constexpr int kRcclInt32 = 2;      // ncclInt32 (rccl.h: ncclDataType_t)
+constexpr int kRcclUint32 = 3;     // ncclUint32 (rccl.h: ncclDataType_t)
 constexpr int kRcclUint64 = 5;     // ncclUint64
 constexpr int kRcclSum = 0;        // ncclSum (ncclRedOp_t)
 
@@ -1256,7 +1264,9 @@ int load_rccl(const char *path, RcclApi *api) {
     struct { const char *name; void **slot; } syms[] = {
         {"ncclGetUniqueId", (void **)&api->GetUniqueId},   {"ncclCommInitRank", (void **)&api->CommInitRank},
         {"ncclAllGather", (void **)&api->AllGather},       {"ncclCommDestroy", (void **)&api->CommDestroy},
-        {"ncclAllReduce", (void **)&api->AllReduce},
+        {"ncclAllReduce", (void **)&api->AllReduce},       {"ncclSend", (void **)&api->Send},
+        {"ncclRecv", (void **)&api->Recv},                 {"ncclGroupStart", (void **)&api->GroupStart},
+        {"ncclGroupEnd", (void **)&api->GroupEnd},
         {"ncclGetErrorString", (void **)&api->GetErrorString},
     };
     for (auto &sy : syms) {
@@ -1265,6 +1275,8 @@ int load_rccl(const char *path, RcclApi *api) {
     }
     return PQPS_OK;
 }
+
+enum : uint8_t { kSlotIdle = 0, kSlotSizesInFlight = 1, kSlotDone = 2, kSlotCount = 3 };
 
 }  // namespace
 
@@ -1275,16 +1287,23 @@ struct pqps_exchange {
     RcclApi rccl;
     void *comm;
     uint32_t world, rank, ring;
-    uint64_t cap, stride;            // IDs per slot; u32 words per slot (header + IDs)
+    uint64_t cap, stride;            // IDs this rank's slot holds; u32 words per slot (header + IDs)
+    uint64_t *caps;                  // [world] every rank's `cap` (they may differ: shards differ by a row)
     hipStream_t stream;              // the exchange stream
-    uint32_t *local;                 // [ring][stride]          this rank's slots
-    uint32_t *slots;                 // [ring][world][stride]   gathered
-    uint32_t *merged;                // [ring][world * cap]
-    uint64_t *totals;                // [ring][2]
-    hipEvent_t *scan_done, *k1_done, *merge_done;
+    uint32_t *local;                 // [ring][stride]   [u64 count][u64 reserved][IDs] of this rank
+    uint64_t *sizes_dev;             // [ring][world]    gathered counts
+    uint64_t *sizes_host;            // [ring][world]    ... on the host (pinned)
+    uint32_t **merged;               // [ring]           the gathered list, grown to what a query needs
+    uint64_t *merged_cap;
+    uint64_t *totals;                // [ring][2]        device: COUNT(*) result
+    uint64_t *totals_host;           // [ring][2]        merged / reported IDs of a SELECT slot
+    hipEvent_t *scan_done, *k1_done, *sizes_done, *merge_done;
     pqps_ctx **child;                // [ring] a context (= filter scratch) per query in flight
-    bool *used;
+    uint8_t *state;
+    uint64_t *issued;                // [ring] call number that last used the slot
+    uint64_t calls;
     uint64_t wait_ns;                // host time spent waiting for a slot to come free
+    uint64_t sizes_wait_ns;          // host time spent waiting for the sizes of a query
 };
 
 int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id) {
@@ -1304,22 +1323,25 @@ int pqps_exchange_destroy(pqps_exchange *x) {
     for (uint32_t i = 0; i < x->ring; i++) {
         if (x->scan_done && x->scan_done[i]) (void)hipEventDestroy(x->scan_done[i]);
         if (x->k1_done && x->k1_done[i]) (void)hipEventDestroy(x->k1_done[i]);
+        if (x->sizes_done && x->sizes_done[i]) (void)hipEventDestroy(x->sizes_done[i]);
         if (x->merge_done && x->merge_done[i]) (void)hipEventDestroy(x->merge_done[i]);
         if (x->child && x->child[i]) pqps_ctx_destroy(x->child[i]);
+        if (x->merged && x->merged[i]) (void)hipFree(x->merged[i]);
     }
-    delete[] x->scan_done; delete[] x->k1_done; delete[] x->merge_done; delete[] x->child; delete[] x->used;
+    delete[] x->scan_done; delete[] x->k1_done; delete[] x->sizes_done; delete[] x->merge_done; delete[] x->child;
+    delete[] x->state; delete[] x->issued; delete[] x->merged; delete[] x->merged_cap; delete[] x->totals_host; delete[] x->caps;
     if (x->local) (void)hipFree(x->local);
-    if (x->slots) (void)hipFree(x->slots);
-    if (x->merged) (void)hipFree(x->merged);
+    if (x->sizes_dev) (void)hipFree(x->sizes_dev);
+    if (x->sizes_host) (void)hipHostFree(x->sizes_host);
     if (x->totals) (void)hipFree(x->totals);
     if (x->stream) (void)hipStreamDestroy(x->stream);
     delete x;
     return PQPS_OK;
 }
 
-int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world, uint32_t rank,
-                         uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
-    if (!ctx || !id || !out) return fail(PQPS_EINVAL, "NULL argument");
+int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t world, uint32_t rank,
+                          uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
+    if (!ctx || !out) return fail(PQPS_EINVAL, "NULL argument");
     if (world == 0 || world > 1024 || rank >= world) return fail(PQPS_EINVAL, "rank %u / world %u out of range", rank, world);
     if (ring == 0 || ring > 64) return fail(PQPS_EINVAL, "ring %u out of range (1..64)", ring);
     if (slot_capacity == 0 || slot_capacity > 0xFFFFFFFFull) return fail(PQPS_EINVAL, "slot capacity out of range");
@@ -1335,78 +1357,209 @@ int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rcc
     X_TRY(hipSetDevice(ctx->device));
     X_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
     X_TRY(hipMalloc((void **)&x->local, (size_t)ring * x->stride * 4));
-    X_TRY(hipMalloc((void **)&x->slots, (size_t)ring * world * x->stride * 4));
-    X_TRY(hipMalloc((void **)&x->merged, (size_t)ring * world * x->cap * 4));
+    X_TRY(hipMalloc((void **)&x->sizes_dev, (size_t)ring * world * sizeof(uint64_t)));
+    X_TRY(hipHostMalloc((void **)&x->sizes_host, (size_t)ring * world * sizeof(uint64_t), hipHostMallocDefault));
     X_TRY(hipMalloc((void **)&x->totals, (size_t)ring * 2 * sizeof(uint64_t)));
     X_TRY(hipMemset(x->local, 0, (size_t)ring * x->stride * 4));
     X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
-    x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->merge_done = new hipEvent_t[ring]();
-    x->child = new pqps_ctx *[ring](); x->used = new bool[ring]();
+    x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->sizes_done = new hipEvent_t[ring]();
+    x->merge_done = new hipEvent_t[ring]();
+    x->child = new pqps_ctx *[ring](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
+    x->merged = new uint32_t *[ring](); x->merged_cap = new uint64_t[ring](); x->totals_host = new uint64_t[2 * (size_t)ring]();
+    x->caps = new uint64_t[world]();
     for (uint32_t i = 0; i < ring; i++) {
         X_TRY(hipEventCreateWithFlags(&x->scan_done[i], hipEventDisableTiming));
         X_TRY(hipEventCreateWithFlags(&x->k1_done[i], hipEventDisableTiming));
+        X_TRY(hipEventCreateWithFlags(&x->sizes_done[i], hipEventDisableTiming));
         X_TRY(hipEventCreateWithFlags(&x->merge_done[i], hipEventDisableTiming));
         if (pqps_ctx_create(ctx->device, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
+        // a first allocation for the gathered list; a query that needs more grows it (never too small)
+        x->merged_cap[i] = x->cap < ((uint64_t)1 << 20) ? x->cap : ((uint64_t)1 << 20);
+        X_TRY(hipMalloc((void **)&x->merged[i], x->merged_cap[i] * 4));
     }
 #undef X_TRY
-    int nrc = x->rccl.CommInitRank(&x->comm, (int)world, *id, (int)rank);
-    if (nrc) {
-        x->comm = nullptr;
-        rc = fail(PQPS_EHIP, "ncclCommInitRank(world %u, rank %u): %s", world, rank, x->rccl.GetErrorString(nrc));
-        pqps_exchange_destroy(x);
-        return rc;
-    }
     *out = x;
     return PQPS_OK;
 }
 
+int pqps_exchange_connect(pqps_exchange *x, const pqps_rccl_id *id) {
+    if (!x || !id) return fail(PQPS_EINVAL, "NULL argument");
+    if (x->comm) return fail(PQPS_EINVAL, "exchange is connected already");
+    (void)hipSetDevice(x->ctx->device);
+    int nrc = x->rccl.CommInitRank(&x->comm, (int)x->world, *id, (int)x->rank);
+    if (nrc) {
+        x->comm = nullptr;
+        return fail(PQPS_EHIP, "ncclCommInitRank(world %u, rank %u): %s", x->world, x->rank, x->rccl.GetErrorString(nrc));
+    }
+    // every rank's slot capacity, once: a rank whose own slot overflowed sends what it holds, and its peers
+    // have to size their receives the same way
+    x->caps[x->rank] = x->cap;
+    if (x->world > 1) {
+        uint64_t *mine = x->sizes_dev, *all = x->sizes_host;      // slot 0's buffers, not in use yet
+        HIP_TRY(hipMemcpyAsync(x->local, &x->cap, sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
+        nrc = x->rccl.AllGather(x->local, mine, 1, kRcclUint64, x->comm, x->stream);
+        if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+        HIP_TRY(hipMemcpyAsync(all, mine, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipMemsetAsync(x->local, 0, sizeof(uint64_t), x->stream));
+        HIP_TRY(hipStreamSynchronize(x->stream));
+        for (uint32_t r = 0; r < x->world; r++) x->caps[r] = all[r];
+    }
+    return PQPS_OK;
+}
+
+int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world, uint32_t rank,
+                         uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
+    if (!id || !out) return fail(PQPS_EINVAL, "NULL argument");
+    pqps_exchange *x = nullptr;
+    int rc = pqps_exchange_prepare(ctx, rccl_library, world, rank, slot_capacity, ring, &x);
+    if (rc) return rc;
+    rc = pqps_exchange_connect(x, id);
+    if (rc) { pqps_exchange_destroy(x); return rc; }
+    *out = x;
+    return PQPS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Second half of a SELECT slot: the sizes are on the host, the payload moves.  Every rank comes through here
+// for the same slots in the same order (the order of its pqps_exchange_* calls).
+int exchange_payload(pqps_exchange *x, uint32_t slot) {
+    if (x->state[slot] != kSlotSizesInFlight) return PQPS_OK;
+    const uint64_t t0 = now_ns();
+    HIP_TRY(hipEventSynchronize(x->sizes_done[slot]));
+    x->sizes_wait_ns += now_ns() - t0;
+    const uint64_t *sizes = x->sizes_host + (uint64_t)slot * x->world;
+    uint64_t total = 0, reported = 0;
+    for (uint32_t r = 0; r < x->world; r++) {                   // mpi:758-762
+        reported += sizes[r];
+        total += sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];  // a rank whose own slot overflowed sends what it holds
+    }
+    if (total > x->merged_cap[slot]) {
+        // the consumer of this slot's previous result is done with it (the slot was handed out again)
+        HIP_TRY(hipStreamSynchronize(x->stream));
+        (void)hipFree(x->merged[slot]);
+        x->merged[slot] = nullptr;
+        x->merged_cap[slot] = 0;
+        const uint64_t want = total + total / 4 + 4096;
+        hipError_t e = hipMalloc((void **)&x->merged[slot], want * 4);
+        if (e != hipSuccess) return fail(PQPS_ENOMEM, "gathered ID list of %llu entries: %s", (unsigned long long)want, hipGetErrorString(e));
+        x->merged_cap[slot] = want;
+    }
+    const uint32_t *mine = x->local + (uint64_t)slot * x->stride + kSlotHeaderWords;
+    uint32_t *merged = x->merged[slot];
+    int nrc = 0;
+    if (x->world > 1) nrc = x->rccl.GroupStart();
+    uint64_t displ = 0;
+    const uint64_t own = sizes[x->rank] < x->cap ? sizes[x->rank] : x->cap;
+    for (uint32_t r = 0; r < x->world && !nrc; r++) {           // mpi:765, as point-to-point pairs
+        const uint64_t k = sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];
+        if (r == x->rank) {
+            if (k) HIP_TRY(hipMemcpyAsync(merged + displ, mine, k * 4, hipMemcpyDeviceToDevice, x->stream));
+        } else {
+            if (own) nrc = x->rccl.Send(mine, (size_t)own, kRcclUint32, (int)r, x->comm, x->stream);
+            if (!nrc && k) nrc = x->rccl.Recv(merged + displ, (size_t)k, kRcclUint32, (int)r, x->comm, x->stream);
+        }
+        displ += k;
+    }
+    if (x->world > 1) { const int end = x->rccl.GroupEnd(); if (!nrc) nrc = end; }
+    if (nrc) return fail(PQPS_EHIP, "ncclSend / ncclRecv: %s", x->rccl.GetErrorString(nrc));
+    x->totals_host[2 * slot] = total;
+    x->totals_host[2 * slot + 1] = reported;
+    HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
+    x->state[slot] = kSlotDone;
+    return PQPS_OK;
+}
+
+// Payload phase of every slot whose sizes are in flight and that was issued before call number `before`,
+// oldest first.
+int exchange_finish_older(pqps_exchange *x, uint64_t before) {
+    for (;;) {
+        int pick = -1;
+        for (uint32_t i = 0; i < x->ring; i++)
+            if (x->state[i] == kSlotSizesInFlight && x->issued[i] < before && (pick < 0 || x->issued[i] < x->issued[pick])) pick = (int)i;
+        if (pick < 0) return PQPS_OK;
+        int rc = exchange_payload(x, (uint32_t)pick);
+        if (rc) return rc;
+    }
+}
+
+// The slot is free again once whatever last used it has finished (a host wait, normally long satisfied).
+int exchange_claim(pqps_exchange *x, uint32_t slot) {
+    if (x->state[slot] == kSlotSizesInFlight) { int rc = exchange_payload(x, slot); if (rc) return rc; }
+    if (x->state[slot] != kSlotIdle) {
+        const uint64_t t0 = now_ns();
+        HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+        x->wait_ns += now_ns() - t0;
+    }
+    x->state[slot] = kSlotIdle;
+    return PQPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
                          const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    if (!x->comm) return fail(PQPS_EINVAL, "exchange is not connected");
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
-    // the slot is free again once the merge that last used it has finished (a host wait, normally
-    // long satisfied: the scan stream carries no cross-stream barrier)
-    if (x->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(x->merge_done[slot])); x->wait_ns += now_ns() - t0; }
-    uint32_t *local = x->local + (uint64_t)slot * x->stride;
-    uint32_t *slots = x->slots + (uint64_t)slot * x->world * x->stride;
-    hipStream_t scan = pick_stream(x->ctx, scan_stream);
     if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
         return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
+    rc = exchange_claim(x, slot);
+    if (rc) return rc;
+    uint32_t *local = x->local + (uint64_t)slot * x->stride;
+    uint64_t *sizes_dev = x->sizes_dev + (uint64_t)slot * x->world;
+    uint64_t *sizes_host = x->sizes_host + (uint64_t)slot * x->world;
+    hipStream_t scan = pick_stream(x->ctx, scan_stream);
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    // K1 on the caller's stream; K2, K3, the all-gather and the merge on the exchange stream behind K1's
-    // completion event, with this slot's own scratch: the caller's stream is free for the next query's K1
-    // at once.  (While the context records timings, the scan runs whole on the caller's stream with the
-    // context's own scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.)
+    // the scan on the caller's stream (its trailing expanders and everything after on the exchange stream,
+    // behind an event, with this slot's own scratch: the caller's stream is free for the next query at once).
+    // (While the context records timings, the scan runs whole on the caller's stream with the context's own
+    // scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.)
     const bool timed = x->ctx->timing;
     rc = run_filter(timed ? x->ctx : x->child[slot], pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS,
                     false, id_base, local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan,
                     timed ? x->scan_done[slot] : nullptr, timed ? nullptr : x->stream, timed ? nullptr : x->k1_done[slot]);
     if (rc) return rc;
     if (timed) HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
-    int nrc = x->rccl.AllGather(local, slots, (size_t)x->stride, kRcclInt32, x->comm, x->stream);   // mpi:753 + mpi:765
-    if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
-    rc = pqps_merge_slots(x->ctx, slots, x->world, x->stride, x->merged + (uint64_t)slot * x->world * x->cap,
-                          x->world * x->cap, x->totals + 2 * (uint64_t)slot, (void *)x->stream);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
-    x->used[slot] = true;
-    return PQPS_OK;
+    // sizes: mpi:753.  They are needed on the host (send / recv counts): an 8-byte-per-rank all-gather, then a
+    // copy into pinned memory behind it
+    if (x->world > 1) {
+        int nrc = x->rccl.AllGather(local, sizes_dev, 1, kRcclUint64, x->comm, x->stream);
+        if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+        HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(sizes_host, local, sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+    }
+    HIP_TRY(hipEventRecord(x->sizes_done[slot], x->stream));
+    x->state[slot] = kSlotSizesInFlight;
+    x->issued[slot] = ++x->calls;
+    // ... and only now the payload of the queries before this one: the host waits for THEIR sizes while the
+    // device already has this query's scan to run.  (With a ring of one there is no query before.)
+    return exchange_finish_older(x, x->issued[slot]);
 }
 
 int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                         const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    if (!x->comm) return fail(PQPS_EINVAL, "exchange is not connected");
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
-    if (x->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(x->merge_done[slot])); x->wait_ns += now_ns() - t0; }
+    int rc = check_pred(cols, n_cols, pred);
+    if (rc) return rc;
+    rc = exchange_claim(x, slot);
+    if (rc) return rc;
+    rc = exchange_finish_older(x, x->calls + 1);                  // collectives stay in call order on every rank
+    if (rc) return rc;
     uint32_t *local = x->local + (uint64_t)slot * x->stride;
     uint64_t *totals = x->totals + 2 * (uint64_t)slot;
     hipStream_t scan = pick_stream(x->ctx, scan_stream);
-    int rc = check_pred(cols, n_cols, pred);
-    if (rc) return rc;
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
@@ -1418,18 +1571,28 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
     int nrc = x->rccl.AllReduce(local, totals, 1, kRcclUint64, kRcclSum, x->comm, x->stream);      // mpi:745
     if (nrc) return fail(PQPS_EHIP, "ncclAllReduce: %s", x->rccl.GetErrorString(nrc));
     HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
-    x->used[slot] = true;
+    x->state[slot] = kSlotCount;
+    x->issued[slot] = ++x->calls;
     return PQPS_OK;
 }
 
 int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
                          uint64_t totals[2]) {
     if (!x || !totals) return fail(PQPS_EINVAL, "NULL argument");
-    if (slot >= x->ring || !x->used[slot]) return fail(PQPS_EINVAL, "slot %u holds no result", slot);
+    if (slot >= x->ring || x->state[slot] == kSlotIdle) return fail(PQPS_EINVAL, "slot %u holds no result", slot);
+    int rc = exchange_finish_older(x, x->issued[slot] + 1);       // up to and including this slot, in call order
+    if (rc) return rc;
     HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
-    HIP_TRY(hipMemcpy(totals, x->totals + 2 * (uint64_t)slot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (local_count) HIP_TRY(hipMemcpy(local_count, x->local + (uint64_t)slot * x->stride, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (merged_dev) *merged_dev = x->merged + (uint64_t)slot * x->world * x->cap;
+    if (x->state[slot] == kSlotCount) {
+        HIP_TRY(hipMemcpy(totals, x->totals + 2 * (uint64_t)slot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (local_count) HIP_TRY(hipMemcpy(local_count, x->local + (uint64_t)slot * x->stride, sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (merged_dev) *merged_dev = nullptr;
+        return PQPS_OK;
+    }
+    totals[0] = x->totals_host[2 * slot];
+    totals[1] = x->totals_host[2 * slot + 1];
+    if (local_count) *local_count = x->sizes_host[(uint64_t)slot * x->world + x->rank];
+    if (merged_dev) *merged_dev = x->merged[slot];
     if (totals[1] > totals[0])
         return fail(PQPS_EOVERFLOW, "exchange slot overflow: %llu IDs reported, capacity %llu per rank",
                     (unsigned long long)totals[1], (unsigned long long)x->cap);
@@ -1438,13 +1601,15 @@ int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merge
 
 uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset) {
     if (!x) return 0;
-    const uint64_t w = x->wait_ns;
-    if (reset) x->wait_ns = 0;
+    const uint64_t w = x->wait_ns + x->sizes_wait_ns;
+    if (reset) x->wait_ns = x->sizes_wait_ns = 0;
     return w;
 }
 
 int pqps_exchange_sync(pqps_exchange *x) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    int rc = exchange_finish_older(x, x->calls + 1);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(x->stream));
     return PQPS_OK;
 }

@@ -5,16 +5,19 @@ exchange mirrors the only row-range data-parallel path of the reference,
 executeQueryDeleteMPI (engine/mpi/executeEngine-mpi.c):
 
     :703-715  block partition of the rows           -> shard_rows()
-    :753      MPI_Allgather of the per-rank sizes   -> the count rides in the slot header
-    :758-762  displacements = exclusive prefix      -> done on the device
-    :765      MPI_Allgatherv of the payload         -> ONE equal-size all_gather of
-              [count | IDs] slots + pqps_merge_slots (device) / torch indexing (CPU)
+    :753      MPI_Allgather of the per-rank sizes   -> an 8-byte-per-rank all_gather
+    :758-762  displacements = exclusive prefix      -> displacements()
+    :765      MPI_Allgatherv of the payload         -> exactly count[r] IDs from every peer, point to
+              point, landing at its displacement (RCCL / torch.distributed have no all-gatherv)
 
 Rank-order concatenation of ascending per-shard lists IS the ascending global
 list, so scan-mode results stay bit-exact with the single-GPU / QPESeq answer.
-RCCL has no all-gatherv; an equal-size all-gather of slots padded to a common
-capacity keeps the whole step free of host round trips (counts never leave the
-device).  A slot overflow is reported in totals[1] > totals[0], never silent.
+Nothing is padded on the wire and no receive buffer can be too small: the sizes
+are known before the payload moves (the gathered list is grown to them).
+
+Two implementations of the same step: ShardExchange (the shim calls RCCL itself,
+include/pqps_hip.h pqps_exchange_*) and IdMerger (torch.distributed collectives:
+the fallback, and the form the CPU tests run under gloo).
 
 torch is plumbing here (device memory, streams, process group).
 """
@@ -29,23 +32,35 @@ def shard_rows(n_rows: int, world: int, rank: int):
     return rem * (base + 1) + (rank - rem) * base, base
 
 
+def displacements(sizes, capacities=None):
+    """mpi:758-762: (what each rank sends, where it lands, total).  A rank whose own buffer was too small
+    (size > its capacity) sends what it holds; the caller sees reported > total."""
+    held = [min(int(s), int(capacities[r])) if capacities is not None else int(s) for r, s in enumerate(sizes)]
+    displ, at = [], 0
+    for h in held:
+        displ.append(at)
+        at += h
+    return held, displ, at
+
+
 SLOT_HEADER_WORDS = 4     # include/pqps_hip.h: [u64 count][u64 reserved] in front of the IDs
 
 
 class IdMerger:
-    """Buffers + the merge for one (world, slot capacity).
+    """Buffers + the exchange for one (world, local capacity), over torch.distributed.
 
-    The filter writes its count to `count_ptr` and its IDs to `ids_ptr` -- both inside this
-    rank's slot -- so ONE equal-size all-gather moves count and payload together; after
-    merge(), `merged[:totals[0]]` on EVERY rank holds the global ascending ID list."""
+    The filter writes its count to `count_ptr` and its IDs to `ids_ptr`; begin() gathers the counts,
+    finish() moves the payload; after that `merged[:totals[0]]` on EVERY rank holds the global ascending
+    ID list.  merge() = begin() + finish().  A caller with several queries in flight calls begin(k) and only
+    then finish(k-1): the host waits for the sizes of k-1 while the device already has k to run."""
 
     def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False,
                  always_collective=False):
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
-        # host_staged: the collective runs on CPU copies (gloo rehearsal of the GPU control flow on a
+        # host_staged: the collectives run on CPU copies (gloo rehearsal of the GPU control flow on a
         # box where RCCL cannot be used, e.g. several ranks sharing one device); never the fast path
         self.host_staged = host_staged
-        self.always_collective = always_collective      # world == 1 still goes through the collective (rehearsal)
+        self.always_collective = always_collective      # world == 1 still goes through the collectives (rehearsal)
         self.cap = int(slot_capacity)
         self.stride = self.cap + SLOT_HEADER_WORDS            # u32 words per slot (even)
         if self.stride % 2:
@@ -55,9 +70,24 @@ class IdMerger:
         self.ctx, self.pq = ctx, pq
         t = torch
         self.slot_local = t.zeros(self.stride, dtype=t.int32, device=device)     # u32 payload, int32 container
-        self.slots = t.zeros(world * self.stride, dtype=t.int32, device=device)
-        self.merged = t.zeros(world * self.cap, dtype=t.int32, device=device)
-        self.totals = t.zeros(2, dtype=t.int64, device=device)
+        self.sizes = t.zeros(world, dtype=t.int64, device=device)
+        self.merged = t.zeros(min(self.cap, 1 << 20), dtype=t.int32, device=device)   # grown to what a query needs
+        self.totals = [0, 0]                                                      # merged, reported
+        self._pending = False
+        self._sizes_pinned = None
+        # every rank's capacity, once (shards differ by a row, so may the capacities): constructing a merger is
+        # a collective step, like every later call
+        self.caps = [self.cap] * world
+        if self._collective() and world > 1:
+            mine = t.tensor([self.cap], dtype=t.int64)
+            parts = [t.zeros_like(mine) for _ in range(world)]
+            if host_staged or device.type != "cuda":
+                dist.all_gather(parts, mine)
+            else:
+                mine = mine.to(device)
+                parts = [p.to(device) for p in parts]
+                dist.all_gather(parts, mine)
+            self.caps = [int(p.item()) for p in parts]
 
     @property
     def count_ptr(self):
@@ -78,41 +108,78 @@ class IdMerger:
     def local_count(self):
         return int(self.slot_local[0:2].cpu().numpy().view("uint64")[0])
 
-    def merge(self, stream_ptr=None):
-        """One collective + compaction, enqueued on the current torch stream."""
+    def _collective(self):
+        return self.world > 1 or self.always_collective
+
+    def begin(self, stream_ptr=None):
+        """mpi:753 -- the sizes, enqueued on the current torch stream."""
         dist, t = self.dist, self.torch
-        if self.world == 1 and not self.always_collective:
-            self.slots.copy_(self.slot_local)
-        elif self.host_staged:
-            loc = self.slot_local.cpu()
+        mine = self.slot_local[0:2].view(t.int64)
+        if not self._collective():
+            self.sizes.copy_(mine)
+        elif self.host_staged or self.device.type != "cuda":
+            loc = mine.cpu()
             parts = [t.zeros_like(loc) for _ in range(self.world)]
             dist.all_gather(parts, loc)
-            self.slots.copy_(t.cat(parts))
+            self.sizes.copy_(t.cat(parts))
         else:
-            dist.all_gather_into_tensor(self.slots, self.slot_local)       # mpi:753 + mpi:765 in one collective
+            dist.all_gather_into_tensor(self.sizes, mine)
         if self.device.type == "cuda":
-            self.pq.check(self.pq.lib().pqps_merge_slots(
-                self.ctx.h, self.slots.data_ptr(), self.world, self.stride,
-                self.merged.data_ptr(), self.merged.numel(), self.totals.data_ptr(), stream_ptr), "pqps_merge_slots")
+            if self._sizes_pinned is None:
+                self._sizes_pinned = t.empty(self.world, dtype=t.int64).pin_memory()
+                self._sizes_ready = t.cuda.Event()
+            self._sizes_pinned.copy_(self.sizes, non_blocking=True)
+            self._sizes_ready.record()
+            self._sizes_host = self._sizes_pinned
         else:
-            # CPU tensors (gloo unit tests): same layout arithmetic in torch
-            displ = raw = 0
+            self._sizes_host = self.sizes
+        self._pending = True
+
+    def finish(self):
+        """mpi:758-765 -- displacements on the host, then exactly count[r] IDs from every peer."""
+        if not self._pending:
+            return
+        self._pending = False
+        dist, t = self.dist, self.torch
+        if self.device.type == "cuda":
+            self._sizes_ready.synchronize()
+        sizes = [int(v) for v in self._sizes_host.tolist()]
+        held, displ, total = displacements(sizes, self.caps)
+        if total > self.merged.numel():
+            self.merged = t.zeros(total + total // 4 + 4096, dtype=t.int32, device=self.device)
+        mine = self.slot_local[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + held[self.rank]]
+        self.merged[displ[self.rank]:displ[self.rank] + held[self.rank]] = mine
+        if self._collective() and self.world > 1:
+            staged = self.host_staged and self.device.type == "cuda"
+            src = mine.cpu() if staged else mine
+            into = t.zeros(total, dtype=t.int32) if staged else self.merged
+            ops = []
             for r in range(self.world):
-                slot = self.slots[r * self.stride:(r + 1) * self.stride]
-                reported = int(slot[0:2].numpy().view("uint64")[0])
-                c = min(reported, self.cap)
-                self.merged[displ:displ + c] = slot[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + c]
-                displ += c
-                raw += reported
-            self.totals[0] = displ
-            self.totals[1] = raw
+                if r == self.rank:
+                    continue
+                if held[self.rank]:
+                    ops.append(dist.P2POp(dist.isend, src, r))
+                if held[r]:
+                    ops.append(dist.P2POp(dist.irecv, into[displ[r]:displ[r] + held[r]], r))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            if staged:
+                for r in range(self.world):
+                    if r != self.rank and held[r]:
+                        self.merged[displ[r]:displ[r] + held[r]] = into[displ[r]:displ[r] + held[r]].to(self.device)
+        self.totals = [total, sum(sizes)]
+
+    def merge(self, stream_ptr=None):
+        self.begin(stream_ptr)
+        self.finish()
 
     def result(self):
         """Host copy of the merged IDs as uint32 numpy (synchronises)."""
-        tot = self.totals.cpu()
-        if int(tot[1]) > int(tot[0]):
-            raise RuntimeError(f"merge slot overflow: {int(tot[1])} IDs reported, capacity {self.cap} per rank")
-        return self.merged[:int(tot[0])].cpu().numpy().view("uint32")
+        self.finish()
+        if self.totals[1] > self.totals[0]:
+            raise RuntimeError(f"local ID buffer overflow: {self.totals[1]} IDs reported, capacity {self.cap} per rank")
+        return self.merged[:self.totals[0]].cpu().numpy().view("uint32")
 
 
 class IndexMerger(IdMerger):
@@ -124,6 +191,9 @@ class IndexMerger(IdMerger):
     def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False):
         super().__init__(torch, dist, world, rank, slot_capacity, device, ctx=ctx, pq=pq, host_staged=host_staged)
         t = torch
+        self.slots = t.zeros(world * self.stride, dtype=t.int32, device=device)     # equal-size [count | IDs] slots
+        self.merged = t.zeros(world * self.cap, dtype=t.int32, device=device)
+        self.totals_dev = t.zeros(2, dtype=t.int64, device=device)
         self.keys_local = t.zeros(self.cap, dtype=t.int64, device=device)          # u64 payload
         self.key_slots = t.zeros(world * self.cap, dtype=t.int64, device=device)
 
@@ -156,7 +226,7 @@ class IndexMerger(IdMerger):
         if self.device.type == "cuda":
             self.pq.check(self.pq.lib().pqps_merge_index_slots(
                 self.ctx.h, self.slots.data_ptr(), self.key_slots.data_ptr(), self.world, self.stride,
-                self.merged.data_ptr(), self.merged.numel(), self.totals.data_ptr(), stream_ptr), "pqps_merge_index_slots")
+                self.merged.data_ptr(), self.merged.numel(), self.totals_dev.data_ptr(), stream_ptr), "pqps_merge_index_slots")
         else:
             import numpy as np
             ids, keys, raw = [], [], 0
@@ -171,8 +241,14 @@ class IndexMerger(IdMerger):
             order = np.lexsort((-(ids.astype(np.int64)), keys))                 # key asc, then row desc
             out = ids[order]
             self.merged[:len(out)] = t.from_numpy(out.view(np.int32).copy())
-            self.totals[0] = len(out)
-            self.totals[1] = raw
+            self.totals = [len(out), raw]
+
+    def result(self):
+        if self.device.type == "cuda":
+            self.totals = [int(v) for v in self.totals_dev.cpu().tolist()]
+        if self.totals[1] > self.totals[0]:
+            raise RuntimeError(f"merge slot overflow: {self.totals[1]} IDs reported, capacity {self.cap} per rank")
+        return self.merged[:self.totals[0]].cpu().numpy().view("uint32")
 
 
 def default_rccl_library(torch=None):
@@ -188,32 +264,97 @@ def default_rccl_library(torch=None):
     return "/opt/rocm/lib/librccl.so"
 
 
+def open_exchange(dist, world, rank, make_id, prepare, connect, close, control_device="cpu", torch=None):
+    """Brings a shim-driven exchange up on every rank or on none -- never on some.
+
+    make_id()      rank 0 only: the RCCL id (bytes), raises on failure
+    prepare()      everything local to a rank (library, streams, buffers), returns a handle, raises on failure
+    connect(h, id) the collective part (ncclCommInitRank blocks until every rank of the world calls it)
+    close(h)       undoes prepare / connect
+
+    A rank that fails locally must not leave the others blocked inside connect(): the ranks agree
+    (all_reduce MIN over torch.distributed) after prepare() and again after connect().  Returns the handle,
+    or None on EVERY rank when any of them failed (the caller then takes the torch.distributed path)."""
+    def agreed(ok):
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=control_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def note(stage, e):
+        import sys
+        print(f"[exchange] rank {rank}: {stage} failed ({e!r}); all ranks fall back to torch.distributed", file=sys.stderr, flush=True)
+
+    box = [None, None]
+    if rank == 0:
+        try:
+            box[0] = make_id()
+        except Exception as e:                                   # noqa: BLE001
+            box[1] = repr(e)
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)                   # rank 0's failure travels with the id
+    if box[1] is not None:
+        if rank == 0:
+            note("RCCL id", box[1])
+        return None
+    handle = None
+    try:
+        handle = prepare()
+    except Exception as e:                                       # noqa: BLE001
+        note("local preparation", e)
+    if not agreed(handle is not None):
+        if handle is not None:
+            close(handle)
+        return None
+    ok = True
+    try:
+        connect(handle, box[0])
+    except Exception as e:                                       # noqa: BLE001
+        note("communicator", e)
+        ok = False
+    if not agreed(ok):
+        close(handle)
+        return None
+    return handle
+
+
 class ShardExchange:
     """Native exchange (include/pqps_hip.h: pqps_exchange_*): ONE host call per query enqueues the
-    shard scan, the RCCL all-gather of the [count | IDs] slot and the device merge (mpi:717-768).
+    shard scan and the all-gatherv of its matching IDs (sizes, then exactly-sized point-to-point payload:
+    mpi:717-768) on the shim's own stream.
 
     torch.distributed is only the bootstrap: rank 0's RCCL id reaches the other ranks through
-    broadcast_object_list; the data path is ncclAllGather called from the shim on its own stream."""
+    broadcast_object_list, and the ranks agree through it that all of them came up (open())."""
 
-    def __init__(self, pq, ctx, torch, dist, world, rank, slot_capacity, ring=4, rccl_library=None):
+    def __init__(self, pq, ctx, handle, world, rank, ring):
+        self.pq, self.ctx, self.h, self.world, self.rank, self.ring = pq, ctx, handle, world, rank, ring
+
+    @classmethod
+    def open(cls, pq, ctx, torch, dist, world, rank, slot_capacity, ring=4, rccl_library=None, control_device="cpu"):
+        """The exchange, or None on every rank if any rank could not set it up."""
         import ctypes as C
-        self.pq, self.ctx, self.world, self.rank, self.ring = pq, ctx, world, rank, ring
         L = pq.lib()
         path = (rccl_library or default_rccl_library(torch)).encode()
-        ident = C.create_string_buffer(128)
-        err = None
-        if rank == 0 and L.pqps_exchange_unique_id(path, ident) != 0:
-            err = "pqps_exchange_unique_id failed: " + L.pqps_last_error().decode()
-        box = [ident.raw, err]                       # rank 0's failure travels with the broadcast: every rank raises
-        if world > 1:
-            dist.broadcast_object_list(box, src=0)
-        if box[1] is not None:
-            raise pq.PqpsError(box[1])
-        ident = C.create_string_buffer(box[0], 128)
-        h = C.c_void_p()
-        pq.check(L.pqps_exchange_create(ctx.h, path, ident, world, rank, int(slot_capacity), ring, C.byref(h)),
-                 "pqps_exchange_create")
-        self.h = h
+
+        def make_id():
+            ident = C.create_string_buffer(128)
+            pq.check(L.pqps_exchange_unique_id(path, ident), "pqps_exchange_unique_id")
+            return ident.raw
+
+        def prepare():
+            h = C.c_void_p()
+            pq.check(L.pqps_exchange_prepare(ctx.h, path, world, rank, int(slot_capacity), ring, C.byref(h)), "pqps_exchange_prepare")
+            return h
+
+        def connect(h, ident):
+            pq.check(L.pqps_exchange_connect(h, C.create_string_buffer(ident, 128)), "pqps_exchange_connect")
+
+        def close(h):
+            L.pqps_exchange_destroy(h)
+
+        h = open_exchange(dist, world, rank, make_id, prepare, connect, close, control_device=control_device, torch=torch)
+        return cls(pq, ctx, h, world, rank, ring) if h is not None else None
 
     def select(self, cols, n_cols, n_rows, id_base, pred_ref, slot, stream_ptr):
         self.pq.check(self.pq.lib().pqps_exchange_select(self.h, cols, n_cols, n_rows, id_base, pred_ref, slot, stream_ptr),
@@ -224,6 +365,10 @@ class ShardExchange:
         self.pq.check(self.pq.lib().pqps_exchange_count(self.h, cols, n_cols, n_rows, pred_ref, slot, stream_ptr),
                       "pqps_exchange_count")
 
+    def sync(self):
+        """Every query handed in so far has been exchanged (enqueues what was still held back, then waits)."""
+        self.pq.check(self.pq.lib().pqps_exchange_sync(self.h), "pqps_exchange_sync")
+
     def count_result(self, slot):
         """(global count, this rank's count) of a count() slot."""
         import ctypes as C
@@ -232,7 +377,7 @@ class ShardExchange:
         return int(totals[0]), int(local.value)
 
     def result(self, slot):
-        """(merged uint32 numpy array, this rank's own match count); waits for the slot's merge."""
+        """(merged uint32 numpy array, this rank's own match count); waits for the slot's exchange."""
         import ctypes as C
         import numpy as np
         ptr, local, totals = C.c_void_p(), C.c_uint64(), (C.c_uint64 * 2)()

@@ -152,6 +152,20 @@ def load_oracle():
 _ref = False
 
 
+_merge = None
+
+
+def pq_merge():
+    """parallel-query-processing-system_amd/merge.py as a module (no torch import of its own)."""
+    global _merge
+    if _merge is None:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("pqps_merge", PKG / "merge.py")
+        _merge = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_merge)
+    return _merge
+
+
 def load_ref():
     """The real reference (+ our harness); None when oracle/_ref was never built."""
     global _ref

@@ -195,9 +195,10 @@ def test_merge_slots_is_the_allgatherv_layout(ctx):
 
 
 def test_native_exchange_world_of_one(ctx):
-    """pqps_exchange_*: scan + ncclAllGather + merge behind one call.  One GPU here, so a world of 1:
-    checks the RCCL plumbing (dlopen, communicator, the collective on the exchange stream), slot
-    reuse round the ring, and that every query's merged list equals the oracle's."""
+    """pqps_exchange_*: scan + sizes + exactly-sized payload behind one call.  One GPU here, so a world of 1:
+    checks the RCCL plumbing (dlopen, two-step bring-up, communicator, the COUNT all-reduce on the exchange
+    stream), the held-back payload phase and slot reuse round the ring, growth of the gathered list, and that
+    every query's merged list equals the oracle's."""
     import importlib.util
     torch = None        # no torch in this process: the shim's HIP runtime is the system one, and so is the RCCL it loads
     spec = importlib.util.spec_from_file_location("pqps_merge", q.PKG / "merge.py")
@@ -208,7 +209,8 @@ def test_native_exchange_world_of_one(ctx):
     dev = pq.SyntheticTable(ctx, n, seed=9)
     names = ["Q_B", "S1", "none", "Q_A", "S7", "Q_B", "neq"]
     want = {k: host.oracle_scan(QUERIES[k]) for k in set(names)}
-    xch = mg.ShardExchange(pq, ctx, torch, None, 1, 0, n, ring=2)
+    xch = mg.ShardExchange.open(pq, ctx, torch, None, 1, 0, n, ring=2)
+    assert xch is not None
     try:
         pending = []
         for i, name in enumerate(names):
@@ -234,9 +236,34 @@ def test_native_exchange_world_of_one(ctx):
     finally:
         xch.close()
         dev.free()
-    # overflow: a slot smaller than the answer is reported, not silently truncated
+    # an answer larger than the first allocation of the gathered list (2^20 IDs): the list grows, nothing is cut;
+    # a ring of three with results read late, and a ring of one (nothing to hide the sizes' round trip behind)
+    n2 = 2_600_003
+    host2 = q.HostSynth(n2, seed=10)
+    dev = pq.SyntheticTable(ctx, n2, seed=10, columns=["sudo_used", "risk_level", "user_name"])
+    dense = [("sudo_used", "=", "FALSE")]
+    for ring in (3, 1):
+        xch = mg.ShardExchange.open(pq, ctx, torch, None, 1, 0, n2, ring=ring)
+        try:
+            plan = [dense, QUERIES["Q_A"], dense, QUERIES["S1"]]
+            for i, chain in enumerate(plan):
+                pred, cols, nc, _ = dev.bind(chain)
+                if i >= ring:
+                    got, _ = xch.result(i % ring)
+                    assert np.array_equal(got, host2.oracle_scan(plan[i - ring]))
+                xch.select(cols, nc, n2, 0, C.byref(pred), i % ring, None)
+            xch.sync()
+            for i in range(max(len(plan) - ring, 0), len(plan)):
+                got, local = xch.result(i % ring)
+                want2 = host2.oracle_scan(plan[i])
+                assert local == len(want2) and np.array_equal(got, want2)
+            assert len(host2.oracle_scan(dense)) > (1 << 20)
+        finally:
+            xch.close()
+    dev.free()
+    # overflow: a slot smaller than the rank's own answer is reported, not silently truncated
     dev = pq.SyntheticTable(ctx, n, seed=9)
-    xch = mg.ShardExchange(pq, ctx, torch, None, 1, 0, 1000, ring=1)
+    xch = mg.ShardExchange.open(pq, ctx, torch, None, 1, 0, 1000, ring=1)
     try:
         pred, cols, nc, _ = dev.bind(QUERIES["neq"])
         xch.select(cols, nc, n, 0, C.byref(pred), 0, None)

@@ -1,10 +1,13 @@
-"""The N > 1 path on CPU: row-range sharding (mpi:703-715) + [count | IDs] slot all-gather
-+ rank-order compaction (merge.py), world_size 2 and 3 over gloo.
+"""The N > 1 path on CPU: row-range sharding (mpi:703-715) + the all-gatherv of the matching IDs as sizes first,
+then exactly-sized point-to-point payload at displacements (merge.py, mirror of mpi:753-765), world_size 2 and 3
+over gloo.
 
 Each rank filters ITS shard with the oracle (the checker stands in for the GPU filter,
 which needs a device), the shards' ascending ID lists are merged on every rank, and
-the result must equal the whole-table oracle answer bit for bit.  Also covers the
-slot-overflow report and the empty-shard / empty-result edges.
+the result must equal the whole-table oracle answer bit for bit.  Covers skewed shards (one rank's rows all
+match while the others' none do), empty shards / empty results, a local buffer that is too small (reported),
+several queries in flight (begin k before finish k-1), and the all-or-none bring-up of the shim-driven
+exchange with a failure injected on one rank.
 """
 import os
 import pathlib
@@ -37,15 +40,34 @@ WORKER = textwrap.dedent("""
         start, count = mg.shard_rows(n, world, rank)
         host = q.HostSynth(count, seed=11, row0=start)
         local = host.oracle_scan(q.chain_from_jsonable(chain), id_base=start)
-        m = mg.IdMerger(torch, dist, world, rank, cap, torch.device("cpu"))
+        m = mg.IdMerger(torch, dist, world, rank, cap + 500 * rank if cap else count + 16, torch.device("cpu"))   # capacities differ by rank
         m.set_local(local)
         m.merge()
         try:
             out[name] = m.result().tolist()
+            assert m.totals[0] == len(out[name]) and m.merged.numel() >= m.totals[0]
         except RuntimeError as e:
-            out[name] = "overflow: " + str(e)
+            # a rank's own buffer was too small: reported, and what every rank DID hold is still gathered in order
+            out[name] = {"error": str(e), "held": m.merged[:m.totals[0]].numpy().view("uint32").tolist(), "caps": m.caps}
+    # several queries in flight, as bench.py drives them: sizes of query k go out before the payload of k-1
+    names = [k for k in cases if k != "overflow"]
+    ring = [mg.IdMerger(torch, dist, world, rank, 60_000, torch.device("cpu")) for _ in range(2)]
+    piped = {}
+    for i, name in enumerate(names):
+        n, chain, _ = cases[name]
+        start, count = mg.shard_rows(n, world, rank)
+        m = ring[i % 2]
+        if i >= 2:
+            piped[names[i - 2]] = m.result().tolist()
+        m.set_local(q.HostSynth(count, seed=11, row0=start).oracle_scan(q.chain_from_jsonable(chain), id_base=start))
+        m.begin()
+        ring[(i - 1) % 2].finish()
+    for i in range(max(len(names) - 2, 0), len(names)):
+        piped[names[i]] = ring[i % 2].result().tolist()
+    assert piped == {k: out[k] for k in names}, "pipelined exchange differs"
     if rank == world - 1:
-        print("RESULT " + json.dumps(out))
+        with open(os.environ["OUT_FILE"], "w") as f:           # (a pipe would fill up: the parent reads the ranks one by one)
+            json.dump(out, f)
     dist.barrier()
     dist.destroy_process_group()
 """)
@@ -65,6 +87,10 @@ def test_sharded_merge_equals_whole_table(world, tmp_path):
         "s1": (50_001, q.chain_to_jsonable([("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")]), 4096),
         "none": (10_000, q.chain_to_jsonable([("risk_level", ">", "9")]), 4096),
         "tiny": (2, q.chain_to_jsonable([("risk_level", ">=", "1")]), 4096),       # some ranks own zero rows
+        # skewed: every row of the first shard matches, none of the others -- and the other way round
+        "first_dense": (30_000, q.chain_to_jsonable([("command_id", "<=", str(30_000 // world))]), 0),
+        "last_dense": (30_000, q.chain_to_jsonable([("command_id", ">", str(30_000 - 30_000 // world))]), 0),
+        "all": (30_001, q.chain_to_jsonable([("risk_level", ">=", "0")]), 0),       # every shard 100 % dense
         "overflow": (50_001, q.chain_to_jsonable([("risk_level", ">=", "1")]), 4096),
     }
     script = tmp_path / "worker.py"
@@ -73,20 +99,98 @@ def test_sharded_merge_equals_whole_table(world, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   CASES=json.dumps(cases), OMP_NUM_THREADS="1")
+                   CASES=json.dumps(cases), OMP_NUM_THREADS="1", OUT_FILE=str(tmp_path / "result.json"))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
-    line = [ln for so, _ in outs for ln in so.splitlines() if ln.startswith("RESULT ")]
-    assert len(line) == 1
-    got = json.loads(line[0][len("RESULT "):])
+    got = json.loads((tmp_path / "result.json").read_text())
     for name, (n, chain, cap) in cases.items():
         want = q.HostSynth(n, seed=11).oracle_scan(q.chain_from_jsonable(chain)).tolist()
         if name == "overflow":
-            assert isinstance(got[name], str) and got[name].startswith("overflow")
+            assert "overflow" in got[name]["error"]
+            caps = got[name]["caps"]
+            assert caps == [4096 + 500 * r + (4096 + 500 * r) % 2 for r in range(world)]
+            held = []
+            for r in range(world):
+                start, count = q.pq_merge().shard_rows(n, world, r)
+                held += [i for i in want if start <= i < start + count][:caps[r]]
+            assert got[name]["held"] == held
         else:
             assert got[name] == want, name
+
+
+BRINGUP_WORKER = textwrap.dedent("""
+    import importlib.util, os, sys, json
+    import torch, torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("pqps_merge", os.path.join(ROOT, "parallel-query-processing-system_amd", "merge.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fail_at, fail_rank = os.environ["FAIL_AT"], int(os.environ["FAIL_RANK"])
+    log = []
+
+    def make_id():
+        if fail_at == "id":
+            raise RuntimeError("injected: no RCCL library")
+        return b"x" * 128
+
+    def prepare():
+        log.append("prepare")
+        if fail_at == "prepare" and rank == fail_rank:
+            raise RuntimeError("injected: hipMalloc failed")
+        return {"rank": rank}
+
+    def connect(h, ident):
+        # stands in for ncclCommInitRank: a collective that returns only when EVERY rank has called it
+        log.append("connect")
+        assert ident == b"x" * 128
+        dist.barrier()
+        if fail_at == "connect" and rank == fail_rank:
+            raise RuntimeError("injected: communicator refused")
+
+    def close(h):
+        log.append("close")
+
+    h = mg.open_exchange(dist, world, rank, make_id, prepare, connect, close, control_device="cpu", torch=torch)
+    print("RESULT " + json.dumps({"rank": rank, "up": h is not None, "log": log}))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("world,fail_at,fail_rank", [(2, "none", 0), (2, "prepare", 1), (3, "prepare", 0), (2, "connect", 1),
+                                                     (3, "id", 0)])
+def test_exchange_comes_up_on_every_rank_or_on_none(world, fail_at, fail_rank, tmp_path):
+    """merge.open_exchange: a rank that fails before the communicator is built must not leave the others
+    blocked inside it (the stand-in connect() is a barrier: it would hang), and a failure of any rank at
+    any stage sends ALL ranks to the fallback."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {str(ROOT)!r}\n" + BRINGUP_WORKER)
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FAIL_AT=fail_at, FAIL_RANK=str(fail_rank), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]                # a hang would trip this timeout
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    res = sorted((json.loads(ln[len("RESULT "):]) for so, _ in outs for ln in so.splitlines() if ln.startswith("RESULT ")),
+                 key=lambda d: d["rank"])
+    assert len(res) == world
+    assert all(d["up"] == (fail_at == "none") for d in res)
+    for d in res:
+        if fail_at == "id":
+            assert d["log"] == []
+        elif fail_at == "prepare":
+            assert "connect" not in d["log"]                       # nobody entered the communicator
+            assert ("close" in d["log"]) == (d["rank"] != fail_rank)
+        elif fail_at == "connect":
+            assert d["log"] == ["prepare", "connect", "close"]
+        else:
+            assert d["log"] == ["prepare", "connect"]
 
 
 def test_shard_rows_is_the_mpi_partition():
