@@ -89,7 +89,23 @@ struct EvalArgs {
     uint8_t on_true[PQPS_MAX_LEAVES];
     uint8_t on_false[PQPS_MAX_LEAVES];
     uint8_t order[PQPS_MAX_LEAVES];
+#ifdef PQPS_STAMPS   /* development builds: wall-clock stamps of tiles and expanders (scripts/stamps.py reads the dump) */
+    uint64_t *stamps;                // [4 header][groups][8][tiles]
+    uint64_t stamp_groups;
+#endif
 };
+
+#ifdef PQPS_STAMPS
+#define PQPS_STAMP_GROUP(a, g, k) do { if ((threadIdx.x & 63) == 0) (a).stamps[4 + (g) * 8 + (k)] = wall_clock64(); } while (0)
+#define PQPS_STAMP_GROUP_MAX(a, g, k) do { if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&(a).stamps[4 + (g) * 8 + (k)], (unsigned long long)wall_clock64()); } while (0)
+#define PQPS_STAMP_VALUE(a, g, k, v) do { if ((threadIdx.x & 63) == 0) (a).stamps[4 + (g) * 8 + (k)] = (v); } while (0)
+#define PQPS_STAMP_TILE(a, t) do { if (threadIdx.x == 0) (a).stamps[4 + (a).stamp_groups * 8 + (t)] = wall_clock64(); } while (0)
+#else
+#define PQPS_STAMP_GROUP(a, g, k) do { } while (0)
+#define PQPS_STAMP_GROUP_MAX(a, g, k) do { } while (0)
+#define PQPS_STAMP_VALUE(a, g, k, v) do { } while (0)
+#define PQPS_STAMP_TILE(a, t) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
@@ -522,7 +538,9 @@ constexpr int kCtlShards = 64, kCtlStride = 32;                     // u32 words
 constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1) * kCtlStride;
 constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
 constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
-constexpr uint32_t kStageRing = 256;        // >= kDirectIds + 63
+constexpr uint32_t kBlockIds = 192;         // FOUR steps with at most this many matches between them are expanded as one block
+                                            // (448 with a ring of 512: Q_A 90 -> 88 us, Q_B 107 -> 110, a lone u8 column 46 -> 47.5 at 100 M rows)
+constexpr uint32_t kStageRing = 256;        // >= max(kDirectIds, kBlockIds) + 63
 constexpr uint32_t kSoloIds = 256;          // a trailing group with at most this many matches is expanded by its leader wave alone
 constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
@@ -612,13 +630,23 @@ __device__ __forceinline__ void zero_other_ctl(const EvalArgs &a) {
     if (a.block_base == 0 && blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
 }
 
-// The calling expander leader has finished group g.  True for exactly one caller of the launch: the last one.
-__device__ __forceinline__ bool last_expander(const EvalArgs &a, uint64_t g, uint64_t groups, uint32_t lane) {
+// Tickets of the expander leaders.  One leader of the launch -- the last to draw -- gets `true` from
+// ticket_is_last.  The draw is a returning atomic on the group's shard (64 shards on their own 128-byte lines:
+// agent-scope atomics that share a line are served one after the other, ~5 ns each); it is issued as soon as the
+// leader has left its wait and travels next to the group's match-word loads, so nothing waits for it alone.
+// Only the last of a shard goes on to the top counter, at the end of its work.
+__device__ __forceinline__ uint32_t ticket_draw(const EvalArgs &a, uint64_t g, uint32_t lane) {
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(a.ctl + (uint32_t)(g % kCtlShards) * kCtlStride, 1u, PQPS_AGENT);
+    return t;
+}
+
+__device__ __forceinline__ bool ticket_is_last(const EvalArgs &a, uint32_t ticket, uint64_t g, uint64_t groups, uint32_t lane) {
     uint32_t last = 0;
     if (lane == 0) {
         const uint32_t shard = (uint32_t)(g % kCtlShards);
         const uint32_t in_shard = (uint32_t)(groups / kCtlShards) + (shard < groups % kCtlShards ? 1u : 0u);
-        if (__hip_atomic_fetch_add(a.ctl + shard * kCtlStride, 1u, PQPS_AGENT) + 1u == in_shard) {
+        if (ticket + 1u == in_shard) {
             const uint32_t shards = groups < (uint64_t)kCtlShards ? (uint32_t)groups : (uint32_t)kCtlShards;
             last = __hip_atomic_fetch_add(a.ctl + kCtlTop, 1u, PQPS_AGENT) + 1u == shards ? 1u : 0u;
         }
@@ -863,7 +891,7 @@ __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &
     return now;
 }
 
-// FOUR consecutive steps at once (4096 rows, at most kDirectIds matches between them): lane L takes rows
+// FOUR consecutive steps at once (4096 rows, at most kBlockIds matches between them): lane L takes rows
 // [64 L, 64 L + 64) of the block -- step L / 16, rows 64 (L % 16) .. of it -- and pulls their 64 match bits out
 // of the parked match words of that step: with RPL rows per lane and chunk they are the same RPL-bit field of
 // 64 / RPL neighbouring lanes' words, i.e. 8, 16 or 32 contiguous bytes of LDS.  One wave scan ranks all IDs of
@@ -979,7 +1007,7 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
             if (!nb) continue;
             const uint32_t sidx0 = w0 + 4 * bb;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
-            if (total <= kDirectIds) {
+            if (total <= kBlockIds) {
                 expand_block<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, rpl_log2, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
             } else {
                 for (uint32_t i = 0; i < 4; i++) {
@@ -1019,7 +1047,9 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
     for (uint32_t spins = 0;; spins++) {
         left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super) : poll_group<NEAR>(a, ex, g, lane, left, cw, psum, own_super);
         light = false;
+        PQPS_STAMP_VALUE(a, g, 4, (uint64_t)spins + 1);
         if (!(left & 1u) && !sum_out) {
+            PQPS_STAMP_GROUP(a, g, 1);
             // the group's matches: normally a tile has summed them up long ago; at the end of the table nobody has
             const uint32_t sum = wave_sum_u32(cw & kCountMask);
             if (lane == 0) st_sc1(a.gsum + g, tag | (uint64_t)sum);
@@ -1126,10 +1156,14 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         const uint64_t w = ld_sc1(a.gsum + g);
         if (word_valid(a, w) && (w & kWordMask) <= kSoloIds) return;        // uniform
     }
+    uint32_t ticket = 0;
     if (leader) {
         uint32_t cw = 0;
         uint64_t psum = 0;
+        PQPS_STAMP_GROUP(a, g, 0);
         ok = settle_group<kNearGroups>(a, ex, g, lane, a.spin_limit, false, cw, psum);
+        PQPS_STAMP_GROUP(a, g, 2);
+        ticket = ticket_draw(a, g, lane);                           // past its wait (a group given up is on record by now)
         if (ok) {
             cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
             group_off = (a.accumulate ? ld_sc1(a.base_slot) : 0ull) + psum;
@@ -1153,8 +1187,9 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         group_off = sh.group_off;
     }
     if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off);
-    // the expander that is last to finish looks after the groups others gave up on (if any)
-    if (leader && last_expander(a, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
+    PQPS_STAMP_GROUP_MAX(a, g, 3);
+    // the leader that was last to leave its wait looks after the groups others gave up on (if any)
+    if (leader && ticket_is_last(a, ticket, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
 }
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
@@ -1187,7 +1222,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic
         }
         if (cnt) drain_stores();
         __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
     } else {
         static_assert(!GATHER, "gather mode produces ID lists");
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
@@ -1450,7 +1485,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
         }
         if (cnt) drain_stores();
         __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -1518,7 +1553,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
         }
         if (any) drain_stores();
         __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); }
+        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;

@@ -630,6 +630,26 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
     const uint64_t slack = gather ? 4 : 0;                        // gather: the device-side range decides; a smaller range can trail up to 3 more groups
     const bool split = tail != nullptr && tail != s && scan_done != nullptr;
+#ifdef PQPS_STAMPS
+    static uint64_t *stamp_buf = nullptr;
+    static size_t stamp_words = 0;
+    const uint64_t n_tiles = groups * tiles_per_group;
+    const size_t want_words = 4 + groups * 8 + n_tiles;
+    if (want_words > stamp_words) { if (stamp_buf) (void)hipFree(stamp_buf); HIP_TRY(hipMalloc((void **)&stamp_buf, want_words * 8)); stamp_words = want_words; }
+    HIP_TRY(hipMemsetAsync(stamp_buf, 0, want_words * 8, s));
+    a.stamps = stamp_buf;
+    a.stamp_groups = groups;
+    struct StampDump { uint64_t *buf; size_t words; uint64_t groups, tpg, lag; hipStream_t s; ~StampDump() {
+        const char *path = getenv("PQPS_STAMPS_FILE");
+        if (!path) return;
+        (void)hipStreamSynchronize(s);
+        uint64_t *host = (uint64_t *)malloc(words * 8);
+        (void)hipMemcpy(host, buf, words * 8, hipMemcpyDeviceToHost);
+        host[0] = groups; host[1] = tpg; host[2] = lag; host[3] = 0;
+        if (FILE *f = fopen(path, "wb")) { fwrite(host, 8, words, f); fclose(f); }
+        free(host);
+    } } stamp_dump{stamp_buf, want_words, groups, tiles_per_group, a.lag, s};
+#endif
     if (!split) {
         hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
         if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
