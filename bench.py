@@ -28,6 +28,12 @@ import pathlib
 import sys
 import time
 
+# The query stream keeps two queries in flight on two HIP streams; they only overlap if the runtime gives the two
+# streams different hardware queues.  ROCm's default pool is 4 queues shared by every stream of the process (torch's
+# included), assigned in an order the host cannot see; with 8 the two lanes never collide.  Has to be in the
+# environment before the HIP runtime starts (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = pathlib.Path(__file__).resolve().parent
 PKG = ROOT / "parallel-query-processing-system_amd"
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -320,6 +326,8 @@ def main():
 
     def drain():
         """Payload phases still held back (the last query's) go out."""
+        if qs is not None:
+            pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
         if xch is not None:
             xch.sync()
         elif exchange and not count_mode:
@@ -423,11 +431,11 @@ def main():
                    "query": sql, "mode": args.mode, "rows_per_gpu": count if strong else args.rows, "rows_total": n_global,
                    "matches_total": total_matches, "selectivity": total_matches / n_global,
                    "bytes_per_row": bytes_per_row, "table_copies_alternated": copies,
-                   "pipelining": ("expanders behind the last scan tile (+ exchange) of query k on a second stream under the scan of query k+1"
+                   "pipelining": ("two queries in flight, each whole on a stream of its own: the tail of query k's launch (+ its exchange) under the scan tiles of query k+1"
                                   if (qs is not None or native) else "none: the queries back to back on one stream"),
                    "parallelism": f"row-range shards x{world}" + (
                        (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} "
-                        + ("all-reduce of the counts" if count_mode else "[count|IDs] all-gather + device merge") + " per query on every rank "
+                        + ("all-reduce of the counts" if count_mode else "all-gatherv of the IDs (sizes, then exactly-sized send/recv at displacements)") + " per query on every rank "
                         + f"({'shim-driven' if native else 'torch.distributed'})") if exchange else ""),
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -436,7 +444,11 @@ def main():
                                 + (" -- the ONE launch of an ID query: scan tiles (the only readers of the table) + expander waves"
                                    if not count_mode else " -- the scan; the one-workgroup reduction of the totals follows it")),
                      "avg_kernel_ms": avg_kernel_ms, "avg_pipeline_ms": pipe_ms / max(launches, 1),
-                     "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes},
+                     "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                     # the same algorithmic bytes over the TIMED region's time per step (queries as they were issued
+                     # for `value`: two in flight, one's tail under the other's scan) -- per GPU
+                     "job_achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9,
+                     "job_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
 
     # side measurements must never cost the headline line

@@ -220,21 +220,26 @@ int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint6
                      uint32_t *merged, uint64_t merged_capacity, uint64_t *totals, void *stream);
 
 /* ---- a stream of queries on one GPU ------------------------------------------------------------------
- * The scan kernel (K1) is bandwidth-bound, the compaction behind it (K2, K3: ~12 us) latency-bound.
- * pqps_qstream_scan is pqps_filter_scan with the two on different streams: K1 on `scan_stream`, K2 / K3 on
- * the query stream's own stream behind K1's completion event, each of the `depth` queries in flight with
- * its own scratch -- so a caller issuing query after query keeps the scan stream busy with K1s back to
- * back (the reference's OpenMP driver issues its queries concurrently, QPEOMP.c:234-291).  Results are
- * complete after pqps_qstream_sync() (or a stream / device synchronise); every query in flight needs its
- * own out_ids / out_count.  The call blocks on the host only to reuse the scratch of the query `depth`
- * calls back. */
+ * An ID query is one launch: scan tiles that read the table at HBM speed, and behind the last of them a tail
+ * in which the last tiles drain and the expanders wait for sums and hand out the last IDs -- 7 us (sparse
+ * answer) to 25 us (dense) of a 100 M-row query in which most of the chip idles.  pqps_qstream_scan is
+ * pqps_filter_scan with TWO queries in flight: each runs whole on one of two HIP streams of the query stream's
+ * own (with a scratch of its own), so the dispatcher fills the slots one query's tail leaves free with the
+ * next query's scan tiles (the reference's OpenMP driver issues its queries concurrently too,
+ * QPEOMP.c:234-291).  `scan_stream` only orders the beginning: the first query after create / sync waits for
+ * what that stream holds at that moment.  Results are complete after pqps_qstream_sync() (or a device
+ * synchronise); the caller keeps a ring of `depth` out_ids / out_count pairs, the call for query k uses pair
+ * k % depth and blocks on the host only until query k - depth has finished.
+ * The two streams must sit on different hardware queues of the runtime: the library asks for
+ * GPU_MAX_HW_QUEUES=8 when it is loaded before the HIP runtime starts; a host that starts HIP first (e.g.
+ * torch) sets that variable itself. */
 typedef struct pqps_qstream pqps_qstream;
 int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out);
 int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
                       const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
                       void *scan_stream);
 int pqps_qstream_sync(pqps_qstream *q);
-/* Host time (ns) pqps_qstream_scan has spent waiting for a slot's scratch to come free -- as opposed to time inside
+/* Host time (ns) pqps_qstream_scan has spent waiting for an output pair to come free -- as opposed to time inside
  * runtime calls; `reset` != 0 clears the counter. */
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset);
 int pqps_qstream_destroy(pqps_qstream *q);

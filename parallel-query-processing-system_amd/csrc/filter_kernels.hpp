@@ -68,11 +68,9 @@ struct EvalArgs {
     uint32_t *out_ids;
     uint64_t out_cap;
     uint64_t *out_count;
-    uint64_t block_base;             // added to blockIdx.x (the trailing expanders can be a launch of their own)
     uint32_t id_base;
     uint32_t lag;                    // groups between a group's scan tiles and its expander in the grid
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
-    uint32_t trail_quads;            // the expanders behind the last tile are quads as well (one wave per group)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -601,7 +599,7 @@ __host__ __device__ inline uint32_t trailing_groups(uint32_t groups, uint32_t la
 template <int TPG>
 __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
     constexpr uint32_t quad_tiles = 4u * TPG, period = quad_tiles + 1u;
-    const uint32_t b = blockIdx.x + (uint32_t)a.block_base;
+    const uint32_t b = blockIdx.x;
     const uint32_t tile_quads = (groups + 3u) / 4u;
     const uint32_t main_blocks = tile_quads * period;
     const uint32_t lag = trailing_groups(groups, a.lag);               // groups with a trailing expander workgroup
@@ -613,8 +611,6 @@ __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
         const uint32_t q = b / period, rr = b % period;
         if (rr < quad_tiles) { r.kind = ROLE_SCAN; r.index = q * quad_tiles + rr; }
         else if (q >= lag_quads) { r.kind = ROLE_EXPAND_QUAD; r.index = q - lag_quads; }   // < quads by construction
-    } else if (a.trail_quads) {                                   // a stream of queries: the trailing groups as quads too (see run_filter)
-        if ((b - main_blocks) * 4u < lag) { r.kind = ROLE_EXPAND_QUAD; r.index = quads + (b - main_blocks); }
     } else if (b - main_blocks < lag) {
         r.kind = ROLE_EXPAND_GROUP;
         r.index = groups - lag + (b - main_blocks);
@@ -627,7 +623,7 @@ __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
 // The two counters of a query (ctl) are the only words that need zeroing: the query does it for the NEXT
 // one, which uses the other half of a ping-pong pair (plain stores: the kernel boundary publishes them).
 __device__ __forceinline__ void zero_other_ctl(const EvalArgs &a) {
-    if (a.block_base == 0 && blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
 }
 
 // Tickets of the expander leaders.  One leader of the launch -- the last to draw -- gets `true` from

@@ -564,14 +564,10 @@ uint32_t expand_spin_limit() {
 //                  workgroups that turn match words into row IDs (filter_kernels.hpp).
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
-               hipEvent_t done = nullptr, hipStream_t tail = nullptr, hipEvent_t scan_done = nullptr) {
+               hipEvent_t done = nullptr) {
     // `done` (optional) becomes ready when the last kernel of this query has finished.  It rides on
     // that kernel's own dispatch packet: a separate hipEventRecord would put a barrier packet behind
     // it and cost the NEXT query on this stream ~7 us of idle queue.
-    // `tail` (optional, ID output): the expanders of the last `lag` groups -- the only part of the query that
-    // cannot run in the shadow of the scan -- are a second launch of the same kernel on that stream, behind
-    // the first one's completion event `scan_done`; the caller's stream is free for the next query's scan at
-    // once (the caller gives every query in flight its own ctx = its own scratch).
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
@@ -594,13 +590,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     if (groups == 0) {
         // no rows at all: the count is the base (0, or unchanged when appending)
         if (!gather) HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint64_t), s));
-        if (tail && tail != s && scan_done) {                       // what follows on `tail` still comes after this query
-            HIP_TRY(hipEventRecord(scan_done, s));
-            HIP_TRY(hipStreamWaitEvent(tail, scan_done, 0));
-            if (done) HIP_TRY(hipEventRecord(done, tail));
-        } else if (done) {
-            HIP_TRY(hipEventRecord(done, s));
-        }
+        if (done) HIP_TRY(hipEventRecord(done, s));
         return PQPS_OK;
     }
     if (ctx->epoch >= 0xFFFFu) {                                 // the tags are about to repeat: start over from "never written"
@@ -625,11 +615,9 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
     if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
     a.spin_limit = expand_spin_limit();
-    a.block_base = 0;
     const uint64_t main_blocks = ((groups + 3) / 4) * (4ull * tiles_per_group + 1), lag = trailing_groups((uint32_t)groups, a.lag);
     if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
     const uint64_t slack = gather ? 4 : 0;                        // gather: the device-side range decides; a smaller range can trail up to 3 more groups
-    const bool split = tail != nullptr && tail != s && scan_done != nullptr;
 #ifdef PQPS_STAMPS
     static uint64_t *stamp_buf = nullptr;
     static size_t stamp_words = 0;
@@ -650,34 +638,25 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         free(host);
     } } stamp_dump{stamp_buf, want_words, groups, tiles_per_group, a.lag, s};
 #endif
-    if (!split) {
-        hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
-        if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
-        else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, a);
-        HIP_TRY(hipGetLastError());
-        if (timed) {
-            ctx->stop_is_eval[ctx->timed] = true;
-            ctx->timed++;
-            if (done) HIP_TRY(hipEventRecord(done, s));
-        }
-        return PQPS_OK;
+    hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
+    if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
+    else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        ctx->stop_is_eval[ctx->timed] = true;
+        ctx->timed++;
+        if (done) HIP_TRY(hipEventRecord(done, s));
     }
-    // The trailing expanders run beside the NEXT query's scan: what they cost it is the wave slots they hold, not
-    // their own duration (measured: a workgroup per group slows a 100 M-row scan from 46 to 58 us).  So here they
-    // are quads -- one wave per group, four groups per workgroup -- like the expanders among the tiles.
-    a.trail_quads = 1;
-    hipExtLaunchKernelGGL(k1, dim3((uint32_t)main_blocks), dim3(kBlock), 0, s, nullptr, scan_done, 0, a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamWaitEvent(tail, scan_done, 0));
-    a.block_base = main_blocks;
-    const uint32_t tail_blocks = (uint32_t)((lag + 3) / 4);
-    if (done) hipExtLaunchKernelGGL(k1, dim3(tail_blocks), dim3(kBlock), 0, tail, nullptr, done, 0, a);
-    else hipLaunchKernelGGL(k1, dim3(tail_blocks), dim3(kBlock), 0, tail, a);
-    HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }
 
 }  // namespace
+
+// Two queries in flight (pqps_qstream, pqps_exchange) need their two HIP streams on different hardware queues.
+// The runtime's pool is 4 queues for all streams of the process by default; ask for 8 unless the host has
+// chosen a number.  Only effective if this library is loaded before the HIP runtime initialises -- a host that
+// starts HIP first (torch) sets GPU_MAX_HW_QUEUES itself (bench.py does).
+__attribute__((constructor)) static void pqps_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 
@@ -716,7 +695,17 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->timed = 0;
     ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
     ctx->stop_is_eval = nullptr;
-    hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t se;
+    if (const char *prio = getenv("PQPS_STREAM_PRIORITY")) {     // experiments: the context's own stream at a given priority
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        int p = atoi(prio);
+        if (p < greatest) p = greatest;
+        if (p > least) p = least;
+        se = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, p);
+    } else {
+        se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    }
     if (se != hipSuccess) { delete ctx; return fail(PQPS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     // sticky status word in mapped host memory: a kernel whose recovery pass gave up sets it, pqps_ctx_sync reports it
     se = hipHostMalloc((void **)&ctx->status_host, 64, hipHostMallocMapped);
@@ -1297,6 +1286,7 @@ int load_rccl(const char *path, RcclApi *api) {
 }
 
 enum : uint8_t { kSlotIdle = 0, kSlotSizesInFlight = 1, kSlotDone = 2, kSlotCount = 3 };
+constexpr uint32_t kExchangeLanes = 2;      // scans in flight, each whole on a stream of its own (as in pqps_qstream)
 
 }  // namespace
 
@@ -1318,7 +1308,9 @@ struct pqps_exchange {
     uint64_t *totals;                // [ring][2]        device: COUNT(*) result
     uint64_t *totals_host;           // [ring][2]        merged / reported IDs of a SELECT slot
     hipEvent_t *scan_done, *k1_done, *sizes_done, *merge_done;
-    pqps_ctx **child;                // [ring] a context (= filter scratch) per query in flight
+    hipEvent_t joined;               // what the caller's stream held when the queries began
+    bool ordered;                    // the lanes already wait for the caller's stream
+    pqps_ctx **child;                // [kExchangeLanes] scratch + HIP stream of the scans in flight (see pqps_qstream)
     uint8_t *state;
     uint64_t *issued;                // [ring] call number that last used the slot
     uint64_t calls;
@@ -1345,9 +1337,11 @@ int pqps_exchange_destroy(pqps_exchange *x) {
         if (x->k1_done && x->k1_done[i]) (void)hipEventDestroy(x->k1_done[i]);
         if (x->sizes_done && x->sizes_done[i]) (void)hipEventDestroy(x->sizes_done[i]);
         if (x->merge_done && x->merge_done[i]) (void)hipEventDestroy(x->merge_done[i]);
-        if (x->child && x->child[i]) pqps_ctx_destroy(x->child[i]);
         if (x->merged && x->merged[i]) (void)hipFree(x->merged[i]);
     }
+    for (uint32_t i = 0; i < kExchangeLanes; i++)
+        if (x->child && x->child[i]) { (void)hipStreamSynchronize(x->child[i]->stream); pqps_ctx_destroy(x->child[i]); }
+    if (x->joined) (void)hipEventDestroy(x->joined);
     delete[] x->scan_done; delete[] x->k1_done; delete[] x->sizes_done; delete[] x->merge_done; delete[] x->child;
     delete[] x->state; delete[] x->issued; delete[] x->merged; delete[] x->merged_cap; delete[] x->totals_host; delete[] x->caps;
     if (x->local) (void)hipFree(x->local);
@@ -1384,7 +1378,10 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
     x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->sizes_done = new hipEvent_t[ring]();
     x->merge_done = new hipEvent_t[ring]();
-    x->child = new pqps_ctx *[ring](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
+    x->child = new pqps_ctx *[kExchangeLanes](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
+    X_TRY(hipEventCreateWithFlags(&x->joined, hipEventDisableTiming));
+    for (uint32_t i = 0; i < kExchangeLanes; i++)
+        if (pqps_ctx_create(ctx->device, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
     x->merged = new uint32_t *[ring](); x->merged_cap = new uint64_t[ring](); x->totals_host = new uint64_t[2 * (size_t)ring]();
     x->caps = new uint64_t[world]();
     for (uint32_t i = 0; i < ring; i++) {
@@ -1392,7 +1389,6 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
         X_TRY(hipEventCreateWithFlags(&x->k1_done[i], hipEventDisableTiming));
         X_TRY(hipEventCreateWithFlags(&x->sizes_done[i], hipEventDisableTiming));
         X_TRY(hipEventCreateWithFlags(&x->merge_done[i], hipEventDisableTiming));
-        if (pqps_ctx_create(ctx->device, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
         // a first allocation for the gathered list; a query that needs more grows it (never too small)
         x->merged_cap[i] = x->cap < ((uint64_t)1 << 20) ? x->cap : ((uint64_t)1 << 20);
         X_TRY(hipMalloc((void **)&x->merged[i], x->merged_cap[i] * 4));
@@ -1539,16 +1535,29 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    // the scan on the caller's stream (its trailing expanders and everything after on the exchange stream,
-    // behind an event, with this slot's own scratch: the caller's stream is free for the next query at once).
-    // (While the context records timings, the scan runs whole on the caller's stream with the context's own
+    // the scan whole on one of two lanes (a stream and a scratch of its own: the tail of one query's launch is
+    // filled by the scan tiles of the next, see pqps_qstream); everything after it on the exchange stream, behind
+    // the launch's own completion event.
+    // (While the context records timings, the scan runs on the caller's stream with the context's own
     // scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.)
     const bool timed = x->ctx->timing;
-    rc = run_filter(timed ? x->ctx : x->child[slot], pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS,
-                    false, id_base, local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan,
-                    timed ? x->scan_done[slot] : nullptr, timed ? nullptr : x->stream, timed ? nullptr : x->k1_done[slot]);
-    if (rc) return rc;
-    if (timed) HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    if (timed) {
+        rc = run_filter(x->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
+                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan, x->scan_done[slot]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    } else {
+        if (!x->ordered) {                                       // what the caller's stream holds (the table, ...) comes first
+            HIP_TRY(hipEventRecord(x->joined, scan));
+            for (uint32_t i = 0; i < kExchangeLanes; i++) HIP_TRY(hipStreamWaitEvent(x->child[i]->stream, x->joined, 0));
+            x->ordered = true;
+        }
+        pqps_ctx *lane = x->child[x->calls % kExchangeLanes];
+        rc = run_filter(lane, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
+                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, lane->stream, x->k1_done[slot]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(x->stream, x->k1_done[slot], 0));
+    }
     // sizes: mpi:753.  They are needed on the host (send / recv counts): an 8-byte-per-rank all-gather, then a
     // copy into pinned memory behind it
     if (x->world > 1) {
@@ -1630,32 +1639,45 @@ int pqps_exchange_sync(pqps_exchange *x) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
     int rc = exchange_finish_older(x, x->calls + 1);
     if (rc) return rc;
+    for (uint32_t i = 0; i < kExchangeLanes; i++) {
+        HIP_TRY(hipStreamSynchronize(x->child[i]->stream));
+        if (*(volatile uint32_t *)x->child[i]->status_host != 0)
+            return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this exchange are incomplete",
+                        *(volatile uint32_t *)x->child[i]->status_host);
+    }
     HIP_TRY(hipStreamSynchronize(x->stream));
+    x->ordered = false;                                          // the caller may have put new work on its stream meanwhile
     return PQPS_OK;
 }
 
-// ---- a stream of queries on one GPU: K1 of query k+1 over K2 / K3 of query k ----------------------
+// ---- a stream of queries on one GPU: two queries in flight, each whole on a HIP stream of its own --------
+// A query's launch ends with a tail the chip is mostly idle in (the last scan tiles drain, the expanders behind
+// them wait for sums and hand out the last IDs: 7 - 25 us of a 100 M-row query) and begins with a ramp.  With
+// the next query already queued on ANOTHER stream the dispatcher fills the slots the tail leaves free with that
+// query's scan tiles.  Measured at 100 M rows, per query: S1 60 -> 52.7 us, Q_A 90 -> 73.5, Q_B 107 -> 90.8, a
+// lone u8 column 46 -> 35.1; a third or fourth stream adds nothing (two scans then run side by side for most
+// of their time and their access windows interleave).  Each lane has its own scratch; results keep the caller's
+// ring of output buffers (`depth` of them: buffer k % depth is free again when query k - depth has finished).
 struct pqps_qstream {
     pqps_ctx *ctx;
-    uint32_t depth;
+    uint32_t depth, lanes;
     uint64_t seq;
-    hipStream_t compact;             // where K2 / K3 run
-    pqps_ctx **child;                // [depth] scratch of the queries in flight
-    hipEvent_t *k1_done, *done;
+    pqps_ctx **child;                // [lanes] scratch + HIP stream of the queries in flight
+    hipEvent_t *done;                // [depth]
+    hipEvent_t joined;               // what the caller's stream held when the stream of queries began
     bool *used;
-    uint64_t wait_ns;                // host time spent waiting for a slot's scratch to come free
+    bool ordered;                    // the lanes already wait for the caller's stream
+    uint64_t wait_ns;                // host time spent waiting for an output buffer to come free
 };
 
 int pqps_qstream_destroy(pqps_qstream *q) {
     if (!q) return PQPS_OK;
-    if (q->compact) (void)hipStreamSynchronize(q->compact);
-    for (uint32_t i = 0; i < q->depth; i++) {
-        if (q->k1_done && q->k1_done[i]) (void)hipEventDestroy(q->k1_done[i]);
+    for (uint32_t i = 0; i < q->lanes; i++)
+        if (q->child && q->child[i]) { (void)hipStreamSynchronize(q->child[i]->stream); pqps_ctx_destroy(q->child[i]); }
+    for (uint32_t i = 0; i < q->depth; i++)
         if (q->done && q->done[i]) (void)hipEventDestroy(q->done[i]);
-        if (q->child && q->child[i]) pqps_ctx_destroy(q->child[i]);
-    }
-    delete[] q->k1_done; delete[] q->done; delete[] q->child; delete[] q->used;
-    if (q->compact) (void)hipStreamDestroy(q->compact);
+    if (q->joined) (void)hipEventDestroy(q->joined);
+    delete[] q->done; delete[] q->child; delete[] q->used;
     delete q;
     return PQPS_OK;
 }
@@ -1666,15 +1688,15 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
     pqps_qstream *q = new (std::nothrow) pqps_qstream();
     if (!q) return fail(PQPS_ENOMEM, "out of host memory");
     q->ctx = ctx; q->depth = depth;
-    q->child = new pqps_ctx *[depth](); q->k1_done = new hipEvent_t[depth](); q->done = new hipEvent_t[depth]();
-    q->used = new bool[depth]();
+    static const int lanes_env = [] { const char *e = getenv("PQPS_QSTREAM_LANES"); return e ? atoi(e) : 0; }();
+    q->lanes = lanes_env >= 1 && lanes_env <= 8 ? (uint32_t)lanes_env : 2u;
+    if (q->lanes > depth) q->lanes = depth;
+    q->child = new pqps_ctx *[q->lanes](); q->done = new hipEvent_t[depth](); q->used = new bool[depth]();
     hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&q->compact, hipStreamNonBlocking);
-    for (uint32_t i = 0; i < depth && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&q->k1_done[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
-        if (e == hipSuccess && pqps_ctx_create(ctx->device, &q->child[i]) != PQPS_OK) { pqps_qstream_destroy(q); return PQPS_EHIP; }
-    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&q->joined, hipEventDisableTiming);
+    for (uint32_t i = 0; i < depth && e == hipSuccess; i++) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
+    for (uint32_t i = 0; i < q->lanes && e == hipSuccess; i++)
+        if (pqps_ctx_create(ctx->device, &q->child[i]) != PQPS_OK) { pqps_qstream_destroy(q); return PQPS_EHIP; }
     if (e != hipSuccess) { pqps_qstream_destroy(q); return fail(PQPS_EHIP, "query stream: %s", hipGetErrorString(e)); }
     *out = q;
     return PQPS_OK;
@@ -1689,20 +1711,31 @@ int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols,
         return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
-    const uint32_t slot = (uint32_t)(q->seq % q->depth);
-    // this slot's scratch is free once the compaction that last used it has finished (a host wait,
-    // `depth` queries back -- normally long satisfied)
-    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->done[slot])); q->wait_ns += now_ns() - t0; }
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
-    hipStream_t scan = pick_stream(q->ctx, scan_stream);
-    const bool timed = q->ctx->timing;                           // see pqps_exchange_select
-    rc = run_filter(timed ? q->ctx : q->child[slot], pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS,
-                    false, id_base, out_ids, out_capacity, out_count, scan, timed ? nullptr : q->done[slot],
-                    timed ? nullptr : q->compact, timed ? nullptr : q->k1_done[slot]);
+    hipStream_t caller = pick_stream(q->ctx, scan_stream);
+    if (q->ctx->timing) {
+        // While the context records timings the query runs whole on the caller's stream with the context's own
+        // scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.
+        return run_filter(q->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
+                          out_ids, out_capacity, out_count, caller);
+    }
+    const uint32_t slot = (uint32_t)(q->seq % q->depth), lane = (uint32_t)(q->seq % q->lanes);
+    // the caller's output buffer `slot` is free once the query that last wrote it has finished (a host wait,
+    // `depth` queries back -- normally long satisfied)
+    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->done[slot])); q->wait_ns += now_ns() - t0; }
+    if (!q->ordered) {                                           // what the caller's stream holds (the table, ...) comes first
+        HIP_TRY(hipEventRecord(q->joined, caller));
+        for (uint32_t i = 0; i < q->lanes; i++) HIP_TRY(hipStreamWaitEvent(q->child[i]->stream, q->joined, 0));
+        q->ordered = true;
+    }
+    pqps_ctx *c = q->child[lane];
+    rc = run_filter(c, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
+                    out_ids, out_capacity, out_count, c->stream, q->done[slot]);
     if (rc) return rc;
-    if (!timed) { q->used[slot] = true; q->seq++; }
+    q->used[slot] = true;
+    q->seq++;
     return PQPS_OK;
 }
 
@@ -1715,7 +1748,13 @@ uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset) {
 
 int pqps_qstream_sync(pqps_qstream *q) {
     if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
-    HIP_TRY(hipStreamSynchronize(q->compact));
+    for (uint32_t i = 0; i < q->lanes; i++) {
+        HIP_TRY(hipStreamSynchronize(q->child[i]->stream));
+        if (*(volatile uint32_t *)q->child[i]->status_host != 0)
+            return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this query stream are incomplete",
+                        *(volatile uint32_t *)q->child[i]->status_host);
+    }
+    q->ordered = false;                                          // the caller may have put new work on its stream meanwhile
     return PQPS_OK;
 }
 
