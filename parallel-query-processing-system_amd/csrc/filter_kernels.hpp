@@ -71,6 +71,7 @@ struct EvalArgs {
     uint32_t id_base;
     uint32_t lag;                    // groups between a group's scan tiles and its expander in the grid
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
+    uint32_t grid_groups;            // gather: groups the grid was sized for (a wider range: the workgroups loop)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -774,55 +775,106 @@ __device__ __forceinline__ uint32_t row_order_word(uint32_t m16, uint32_t lane) 
     }
 }
 
+// Row-ordered match word of a step (lane d: rows 16 d .. 16 d + 15) from the scan's load layout.
+__device__ __forceinline__ uint32_t step_row_word(uint32_t m16, uint32_t rpl_log2, uint32_t lane) {
+    switch (rpl_log2) {                                             // uniform
+    case 2: return row_order_word<2>(m16, lane);
+    case 3: return row_order_word<3>(m16, lane);
+    default: return m16;
+    }
+}
+
+// The match bits of rows 64 s .. 64 s + 63 of a step are the words of lanes 4 s .. 4 s + 3: wave-uniform lane
+// numbers, so v_readlane (SGPR result), no LDS crossbar.
+__device__ __forceinline__ uint64_t sub_block_bits(uint32_t word, uint32_t s) {
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s));
+    const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 1));
+    const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 2));
+    const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 3));
+    return (uint64_t)(w0 | (w1 << 16)) | ((uint64_t)(w2 | (w3 << 16)) << 32);
+}
+
+// Gather (index mode): the candidate numbers of a dense step's matching rows, all 16 sub-blocks requested at once
+// (lane L of sub-block s <-> row 64 s + L; a set bit implies the row lies inside the probed range): one memory
+// latency per step instead of one per sub-block.
+__device__ __forceinline__ void gather_candidates(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t lane, uint32_t (&cnd)[16]) {
+    const uint32_t step_row0 = (uint32_t)(step * kStepRows);
+#pragma unroll
+    for (uint32_t s = 0; s < 16; s++) {
+        // every lane loads (a lane without a match: the range's first candidate, always there) -- exactly 16 load
+        // instructions per step, so the waits further down can be counted instead of being "for everything"
+        const uint64_t b = sub_block_bits(word, s);
+        const uint32_t row = ((b >> lane) & 1ull) ? step_row0 + 64u * s + lane : 0u;
+        cnd[s] = a.cand[begin + row];
+    }
+}
+
+// A step with many matches: 64 rows at a time, rank inside the 64 = mbcnt, so the lanes store to consecutive slots.
+template <bool GATHER>
+__device__ __forceinline__ void expand_step_dense(const EvalArgs &a, uint64_t step, uint32_t word, uint32_t lane, uint32_t *ring, OutRing &r,
+                                                  const uint32_t (&cnd)[16]) {
+    const uint32_t step_row0 = (uint32_t)(step * kStepRows);
+    if (r.pending) ring_flush(a, ring, r, lane, r.pending);         // < 64 staged IDs from the steps before
+    auto sub_block = [&](uint32_t s, uint32_t cand_id) {
+        const uint64_t b = sub_block_bits(word, s);
+        if (b) {                                                    // uniform
+            if ((b >> lane) & 1ull) {
+                const uint64_t o = r.pos + mbcnt(b);
+                const uint32_t id = GATHER ? cand_id : step_row0 + 64u * s + lane;
+                if (o < a.out_cap) a.out_ids[o] = id + a.id_base;
+            }
+            r.pos += (uint64_t)__popcll(b);
+        }
+    };
+    if constexpr (GATHER) {
+#pragma unroll
+        for (uint32_t s = 0; s < 16; s++) sub_block(s, cnd[s]);     // (the numbers sit in 16 registers)
+    } else {
+#pragma unroll 1
+        for (uint32_t s = 0; s < 16; s++) sub_block(s, 0u);         // a loop: the scan tiles' code wants the instruction cache
+    }
+}
+
+// A step with few matches: one wave scan of the per-lane popcounts gives every lane its rank; the IDs go to the ring.
+template <bool GATHER>
+__device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t count, uint32_t lane,
+                                                   uint32_t *ring, OutRing &r) {
+    const uint32_t step_row0 = (uint32_t)(step * kStepRows);
+    const uint32_t cnt = __popc(word);
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    uint32_t slot = r.head + r.pending + (incl - cnt);
+    const uint32_t r0 = step_row0 + lane * 16u;
+    while (word) {                                                  // set bits only, ascending rows
+        const uint32_t j = (uint32_t)__builtin_ctz(word);
+        word &= word - 1;
+        // gather: the candidate number of the row (a set bit implies the row lies inside the probed range)
+        uint32_t id = r0 + j;
+        if constexpr (GATHER) id = a.cand[begin + r0 + j];
+        ring[slot & (kStageRing - 1)] = id + a.id_base;
+        slot++;
+    }
+    r.pending += count;
+    while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
+}
+
 template <bool GATHER>
 __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t m16, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
-    uint32_t word;
-    switch (rpl_log2) {                                             // uniform
-    case 2: word = row_order_word<2>(m16, lane); break;
-    case 3: word = row_order_word<3>(m16, lane); break;
-    default: word = m16; break;
-    }
-    const uint32_t step_row0 = (uint32_t)(step * kStepRows);
+    const uint32_t word = step_row_word(m16, rpl_log2, lane);
     if (count <= kDirectIds) {
-        const uint32_t cnt = __popc(word);
-        const uint32_t incl = wave_incl_scan_u32(cnt);
-        uint32_t slot = r.head + r.pending + (incl - cnt);
-        const uint32_t r0 = step_row0 + lane * 16u;
-        while (word) {                                              // set bits only, ascending rows
-            const uint32_t j = (uint32_t)__builtin_ctz(word);
-            word &= word - 1;
-            // gather: the candidate number of the row (a set bit implies the row lies inside the probed range)
-            uint32_t id = r0 + j;
-            if constexpr (GATHER) id = a.cand[begin + r0 + j];
-            ring[slot & (kStageRing - 1)] = id + a.id_base;
-            slot++;
-        }
-        r.pending += count;
-        while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
-    } else {
-        if (r.pending) ring_flush(a, ring, r, lane, r.pending);     // < 64 staged IDs from the steps before
-#pragma unroll 1
-        for (uint32_t s = 0; s < 16; s++) {
-            // the match bits of rows 64s .. 64s+63 are the words of lanes 4s .. 4s+3: wave-uniform lane numbers, so
-            // v_readlane (SGPR result), no LDS crossbar
-            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s));
-            const uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 1));
-            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 2));
-            const uint32_t w3 = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)(4 * s + 3));
-            const uint64_t b = (uint64_t)(w0 | (w1 << 16)) | ((uint64_t)(w2 | (w3 << 16)) << 32);
-            if (b) {                                                // uniform
-                if ((b >> lane) & 1ull) {
-                    const uint64_t o = r.pos + mbcnt(b);
-                    const uint32_t row = step_row0 + 64u * s + lane;
-                    uint32_t id = row;
-                    if constexpr (GATHER) id = a.cand[begin + row];
-                    if (o < a.out_cap) a.out_ids[o] = id + a.id_base;
-                }
-                r.pos += (uint64_t)__popcll(b);
-            }
-        }
+        expand_step_sparse<GATHER>(a, begin, step, word, count, lane, ring, r);
+        return;
     }
+    uint32_t cnd[16];
+    if constexpr (GATHER) {
+        gather_candidates(a, begin, step, word, lane, cnd);
+        // All 16 numbers in before the first store goes out: gfx9's vmcnt counts loads and stores in ONE in-order
+        // queue, so a wait for a load that is placed between stores also waits for the stores' acknowledgements
+        // (measured: 2.8 us per step when the compiler places one wait per sub-block; requesting the NEXT step's
+        // numbers early does not help either -- taking them over means a wait behind this step's stores).
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+    }
+    expand_step_dense<GATHER>(a, step, word, lane, ring, r, cnd);
 }
 
 __device__ __forceinline__ bool word_valid(const EvalArgs &a, uint64_t w) { return (uint32_t)(w >> kWordEpochShift) == a.epoch; }
@@ -974,6 +1026,7 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
             if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler does not count LDS-DMA as a write to LDS)
+        if (c0 == 0) PQPS_STAMP_GROUP(a, g, 5);
         k = 0;
         for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {
             const uint32_t st = (uint32_t)__builtin_ctzll(rest);
@@ -982,6 +1035,7 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
         }
         if (r.pending) ring_flush(a, ring, r, lane, r.pending);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c0 == 0) PQPS_STAMP_GROUP(a, g, 6);
         return;
     }
     for (uint32_t w0 = c0; w0 < c1; w0 += kGroupSteps / kWaves) {   // 16 steps at a time
@@ -1134,7 +1188,7 @@ __device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared 
 
 // An expander workgroup.  Among the scan tiles: four independent waves, one group each.  Behind the last tile:
 // one group, its leader wave settles it and hands count words and output slot to the other three through LDS.
-template <bool GATHER>
+template <bool GATHER, bool LOOPED = false>                     // LOOPED: called again for further groups -- every wave reaches the barrier
 __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShared &sh, const Extent &ex, const Role &role) {
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
@@ -1145,7 +1199,7 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     bool ok = false;
     uint32_t cnts = 0;
     uint64_t group_off = 0;
-    if (shared && !leader) {
+    if (shared && !leader && !LOOPED) {
         // A group with few matches is its leader's alone: the other three waves leave as soon as they know (from the
         // group's sum, which a tile has published long ago unless this is the end of the table) -- a wave that waits
         // at the barrier holds a slot the next query's scan could use.
@@ -1190,35 +1244,59 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
 template <int MODE, bool GATHER, bool NT = false>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 4 : 1) void eval_generic_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) void eval_generic_kernel(const EvalArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves;                              // steps per tile
         __shared__ FusedShared sh;
         zero_other_ctl(a);
         const Extent ex = scan_extent<GATHER>(a);
-        const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<GATHER>(a, sh, ex, role); return; }
-        if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
-        const uint64_t step = (uint64_t)role.index * TS + wv;
-        const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);
-        uint32_t cnt = 0;
-        if (step < ex.steps) {
-            const uint64_t step_row0 = step * kStepRows;
-            uint32_t mbits;
-            if (GATHER) mbits = eval_step_guarded<true>(a, step_row0, ex.n_rows, ex.begin, lane);
-            else {
-                mbits = eval_step_full<NT>(a, step_row0, lane);
-                if (step_row0 + kStepRows > ex.n_rows) mbits &= rows_below<kRplGeneric>(step_row0, ex.n_rows, lane);   // the partial last step
+        // Gather: the probed range is known on the device only, and a grid sized for the caller's upper bound (the
+        // whole table) would spend tens of microseconds dispatching workgroups that find nothing to do.  The host
+        // sizes the grid for at most a.grid_groups groups; a wider range is covered by every workgroup taking its
+        // role again `layout` groups (tiles) further on.  (Scan tiles wait for nothing and the expanders come after
+        // them in the grid, so the expanders' bounded waits always end.)
+        const uint32_t layout = GATHER && ex.groups > a.grid_groups ? a.grid_groups : (uint32_t)ex.groups;
+        const Role role = fused_role<kGroupSteps / TS>(a, layout);
+        if (role.kind >= ROLE_EXPAND_QUAD) {
+            if constexpr (GATHER) {
+                Role r = role;                                      // (gather launches have no expanders among the tiles)
+                for (;;) {
+                    expander_workgroup<GATHER, true>(a, sh, ex, r);
+                    r.index += layout;
+                    if (role.kind != ROLE_EXPAND_GROUP || r.index >= ex.groups) break;
+                    __syncthreads();                                // the workgroup's LDS hand-over is free again
+                }
+            } else {
+                expander_workgroup<GATHER>(a, sh, ex, role);
             }
-            cnt = wave_sum_u32(__popc(mbits));
-            tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
-        } else if (lane == 0) {
-            sh.tile_cnt[wv] = 0;
+            return;
         }
-        if (cnt) drain_stores();
-        __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
+        if (role.kind != ROLE_SCAN) return;
+        const uint32_t layout_tiles = ((layout + 3u) / 4u) * 4u * (uint32_t)(kGroupSteps / TS);
+        for (uint64_t tile = role.index; tile * TS < ex.steps; tile += layout_tiles) {
+            const uint64_t step = tile * TS + wv;
+            const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, (uint32_t)tile, wv, lane);
+            uint32_t cnt = 0;
+            if (step < ex.steps) {
+                const uint64_t step_row0 = step * kStepRows;
+                uint32_t mbits;
+                if (GATHER) mbits = eval_step_guarded<true>(a, step_row0, ex.n_rows, ex.begin, lane);
+                else {
+                    mbits = eval_step_full<NT>(a, step_row0, lane);
+                    if (step_row0 + kStepRows > ex.n_rows) mbits &= rows_below<kRplGeneric>(step_row0, ex.n_rows, lane);   // the partial last step
+                }
+                cnt = wave_sum_u32(__popc(mbits));
+                tile_step_out(a, sh, wv, step, cnt, mbits, 2, lane);
+            } else if (lane == 0) {
+                sh.tile_cnt[wv] = 0;
+            }
+            if (cnt) drain_stores();
+            __syncthreads();
+            if (wv == 0) { publish_tile<TS>(a, sh, ex, tile, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, tile); }
+            if (!GATHER) break;                                     // a scan's grid covers every tile
+            __syncthreads();                                        // sh.tile_cnt is free again
+        }
     } else {
         static_assert(!GATHER, "gather mode produces ID lists");
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;

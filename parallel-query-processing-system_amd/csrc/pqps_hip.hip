@@ -562,6 +562,8 @@ uint32_t expand_spin_limit() {
 //   COUNT / FLAGS: the scan kernel + a one-workgroup reduction of the workgroup totals.
 //   ID output:     ONE launch -- scan tiles and, `lag` groups behind them in the grid, the expander
 //                  workgroups that turn match words into row IDs (filter_kernels.hpp).
+constexpr uint64_t kGatherGridGroups = 64;
+
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
                hipEvent_t done = nullptr) {
@@ -571,7 +573,10 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
-    const uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+    uint64_t groups = (steps + kGroupSteps - 1) / kGroupSteps;
+    // gather: `rows` is only an upper bound (the probed range lives on the device).  The grid is sized for at most
+    // kGatherGridGroups groups (4 M candidates); the kernel's workgroups loop if the range turns out wider.
+    if (gather && mode == MODE_IDS && groups > kGatherGridGroups) groups = kGatherGridGroups;
     a.masks = ctx->masks;
     a.counts = ctx->counts;
     a.partials = ctx->partials;
@@ -610,7 +615,8 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.id_base = id_base;
     a.accumulate = gather ? 1u : 0u;
     const uint32_t tiles_per_group = (uint32_t)kGroupSteps / ((uint32_t)kWaves * (a.steps_per_iter ? a.steps_per_iter : 1u));
-    a.lag = expand_lag(ctx, tiles_per_group, groups);
+    a.lag = gather ? 0x7FFFFFFFu : expand_lag(ctx, tiles_per_group, groups);   // (a looping gather grid has all its expanders behind its tiles)
+    a.grid_groups = (uint32_t)groups;
     a.sum_lag = expand_sum_lag(ctx, tiles_per_group);
     if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
     if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
