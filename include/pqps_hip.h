@@ -25,9 +25,10 @@
  *   pqps_index_probe    findLeaf + the leaf walk of findRange (bplus.c:282-358).
  *   pqps_partition      the block partition of engine/mpi/executeEngine-mpi.c:703-715.
  *   pqps_exchange_*     the per-query exchange of the MPI engine (executeEngine-mpi.c:717-768:
- *                       local scan of the rank's rows, MPI_Allgather + MPI_Allgatherv; :745
- *                       MPI_Allreduce for counts) as shard scan + ONE RCCL collective.
- *   pqps_merge_slots    the displacement arithmetic + placement of MPI_Allgatherv (:758-765).
+ *                       local scan of the rank's rows, MPI_Allgather of the sizes + MPI_Allgatherv of
+ *                       the IDs; :745 MPI_Allreduce for counts) over RCCL, same shape.
+ *   pqps_merge_slots    the displacement arithmetic + placement of MPI_Allgatherv (:758-765) for
+ *                       equal-size slots (index mode across processes).
  *   pqps_compact_rows   the survivor compaction of DELETE (executeEngine-serial.c:646-680).
  *   pqps_bump_codes     (no counterpart: keeps dictionary codes order-preserving on INSERT).
  *
@@ -108,14 +109,12 @@ int  pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
 /* Per-launch HIP-event timing of the filter (up to 4096 launches per reset).
- * The evaluate kernel (K1, the only kernel that reads the table) carries its
- * own begin / end events on the dispatch packet, i.e. the timestamps rocprofv3
- * --kernel-trace reports; a third event is recorded after the last kernel.
- * pqps_ctx_kernel_time waits for the recorded launches and returns: *eval_ms =
- * sum of the K1 durations, *total_ms = sum over the whole K1 -> K2 -> K3
- * pipeline, and their number; it then resets the recorder.  While timing is on,
- * pqps_qstream_scan / pqps_exchange_select run each query whole on the caller's
- * stream with the context's own scratch (so that the events mean the above):
+ * The scan kernel carries its own begin / end events on the dispatch packet, i.e. the timestamps rocprofv3
+ * --kernel-trace reports.  pqps_ctx_kernel_time waits for the recorded launches and returns: *eval_ms = sum of
+ * the scan-kernel durations, *total_ms = sum over the whole query, and their number; it then resets the recorder.
+ * An ID query is ONE launch (scan tiles + expanders): eval_ms == total_ms; COUNT(*) / flags add the
+ * one-workgroup reduction behind the scan.  While timing is on, pqps_qstream_scan / pqps_exchange_select run
+ * each query whole on the caller's stream with the context's own scratch (so that the events mean the above):
  * issue them on ONE stream then. */
 int  pqps_ctx_set_timing(pqps_ctx *ctx, int enable);
 int  pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *launches);
@@ -136,8 +135,11 @@ int pqps_bump_codes(pqps_ctx *ctx, void *codes, uint32_t width, uint64_t n_rows,
 
 /* Scan mode.  Evaluates `pred` on rows [0, n_rows) of `cols` and writes the
  * matching row IDs (row + id_base, u32) in ASCENDING row order to out_ids and
- * their number to *out_count (device u64).  Asynchronous on `stream`.
- * Columns must be readable up to n_rows rounded up to 16 bytes. */
+ * their number to *out_count (device u64).  Asynchronous on `stream`.  One launch.
+ * Columns must be readable up to n_rows rounded up to PQPS_STEP_ROWS (1024) rows: the last, partial step is
+ * loaded whole and masked.  A launch whose bounded internal waits ran out (never seen with in-order
+ * dispatch) sets the context's sticky status word: pqps_ctx_sync then fails with PQPS_EHIP. */
+#define PQPS_STEP_ROWS 1024
 int pqps_filter_scan(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
                      uint64_t n_rows, uint32_t id_base, const pqps_predicate *pred,
                      uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,

@@ -13,22 +13,25 @@
 //            ones dwordx2 / dword / ushort loads that are just as contiguous across the wave.  A leaf is
 //            the unsigned window test ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth
 //            table (<= 6 leaves) or a jump table.  Output per step: 16 match bits per lane (128 bytes,
-//            skipped when the step has no match) and the step's match count; per tile ONE agent-scope
-//            atomic add of (steps, matches) to the word of its GROUP (64 steps = 64 K rows).
-//  expand    a workgroup per group, placed in the grid `lag` groups behind the group's scan tiles: waits
-//            (normally not at all) until its group and everything in front of it has arrived, derives
-//            its first output slot from the supergroup words (64 groups each) and the earlier group
-//            words of its own supergroup, and turns the match bits into ascending row IDs.  Its integer
-//            work runs in the shadow of the bandwidth-bound scan tiles around it; only the last `lag`
-//            groups are expanded after the last table byte has been read.
+//            skipped when the step has no match); per tile ONE store of its steps' COUNT WORDS
+//            (epoch << 16 | log2(RPL) << 11 | matches) by wave 0 after the tile's barrier.  The first two
+//            tiles of a group also do SUM DUTY for a group / supergroup `sum_lag` groups back (a hint).
+//  expand    turns the match bits of a GROUP (64 steps = 64 K rows) into ascending row IDs.  It needs the
+//            group's count words (all tagged with this query's epoch => its match words are in memory)
+//            and the matches in front of it: supergroup sums (64 groups each) + the earlier group sums of
+//            its own supergroup -- tagged words published by the tiles' sum duty or, failing that, by the
+//            groups' own expanders.  Placed behind the last tile (a workgroup per group) or, for large
+//            tables, `lag` groups behind the group's tiles (a wave per group), where its integer work
+//            runs in the shadow of the bandwidth-bound scan.
 //
-// Hand-off between the roles follows the write-through form of the CDNA4 guide: payload (match bits,
-// step counts) stored sc1, every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's
-// barrier, one lane signals with an agent-scope atomic; the consumer polls with sc1 loads and reads the
-// payload with sc1 loads only.  No result depends on dispatch order: an expander's wait is bounded, a
-// group whose wait ran out is left to the expander that is last to leave its wait (one workgroup, so it
-// cannot starve the tiles it waits for), and the words of a query are zeroed by the next query on the
-// other half of a ping-pong pair.
+// Hand-off between the roles follows the write-through form of the CDNA4 guide and uses NO atomics: payload
+// (match bits) stored sc1, every storing wave drains (s_waitcnt vmcnt(0)) before the workgroup's barrier,
+// one wave publishes the epoch-tagged count words; the consumer polls with sc1 loads and reads the payload
+// with sc1 loads only.  Nothing has to be reset between queries (a stale word carries an older epoch).  No
+// result depends on dispatch order: an expander's wait is bounded, a group whose wait ran out is left to
+// the leader that is last to leave its wait (tickets: sharded atomics, the only ones in the launch; their
+// two words are zeroed by the query before, on the other half of a ping-pong pair), and a wait that never
+// ends there sets the context's sticky status word.
 //
 // COUNT(*) / DELETE flags keep the grid-stride form of the scan (no ID list, no hand-off).
 // Width-specialised instantiations (1-3 predicate columns, widths non-increasing) keep all loads

@@ -5,7 +5,7 @@
 #   PQPS_K1_ITERS=<float>        grid of K1 as iterations per wave (default: 1 when streaming, 1.5 otherwise)
 #   PQPS_K1_BLOCKS_PER_CU=<int>  grid cap of K1 per CU
 #   PQPS_CHAIN_MULTI=0|1         several steps per loop iteration for a lone 1-byte column
-#   PQPS_K3_WAVE_GROUPS=<int>    group count from which K3 runs one group per wave (default 8192)
+#   PQPS_SUM_LAG, PQPS_EXPAND_LAG, PQPS_EXPAND_SPIN_LIMIT, PQPS_QSTREAM_LANES: see scripts/README.md
 var=$1; shift
 vals=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
