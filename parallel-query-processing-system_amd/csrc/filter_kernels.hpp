@@ -1214,7 +1214,12 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         uint32_t cw = 0;
         uint64_t psum = 0;
         PQPS_STAMP_GROUP(a, g, 0);
+        // A leader's polls come first on its SIMD: behind the last tile the neighbouring waves are busy expanding
+        // (the vector units are the bottleneck there), and the sums this leader publishes are what other groups wait
+        // for (a lone u8 column at 100 M rows: last group settled 9.1 -> 3.8 us after the last tile).
+        __builtin_amdgcn_s_setprio(3);
         ok = settle_group<kNearGroups>(a, ex, g, lane, a.spin_limit, false, cw, psum);
+        __builtin_amdgcn_s_setprio(0);
         PQPS_STAMP_GROUP(a, g, 2);
         ticket = ticket_draw(a, g, lane);                           // past its wait (a group given up is on record by now)
         if (ok) {
