@@ -313,13 +313,14 @@ def main():
                     dist.all_reduce(t)
                     count_all[r] = t[0]
             else:
-                # sizes of query k first, then the payload of query k-1: the host's wait for those sizes falls
-                # under this query's scan (same order as the shim-driven exchange)
+                # sizes of query k, then the payload of the query three calls back, whose sizes have long reached
+                # the host (same order as the shim-driven exchange: the host never waits for a scan that still runs)
                 m.begin(stream_ptr=comm.cuda_stream)
-                prev = mergers[(k - 1) % RING]
-                if prev is not m and prev._pending:
+                back = 3 if RING >= 5 else (2 if RING == 4 else 1)
+                prev = mergers[(k - back) % RING]
+                if k >= back and prev is not m and prev._pending:
                     prev.finish()
-                    merge_done[(k - 1) % RING].record(comm)
+                    merge_done[(k - back) % RING].record(comm)
                 if RING == 1:
                     m.finish()
             merge_done[r].record(comm)
@@ -332,7 +333,7 @@ def main():
             xch.sync()
         elif exchange and not count_mode:
             with torch.cuda.stream(comm):
-                for j in range(RING):
+                for j in sorted(range(RING), key=lambda i: mergers[i]._issued):       # oldest first, on every rank alike
                     if mergers[j]._pending:
                         mergers[j].finish()
                         merge_done[j].record(comm)
@@ -477,7 +478,7 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-RING = 4      # result slots in flight: query k's merge runs under the scans of queries k+1 ..
+RING = 6                       # result slots in flight (the exchange holds two queries' payload back: needs >= 5)
 
 # the kernel instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
 K_NAMES = {("S1", "ids"): "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT, VC=false>",

@@ -268,10 +268,12 @@ int pqps_qstream_destroy(pqps_qstream *q);
  *   scan_stream     : the filter launch, writing [count | IDs] into ring slot `slot` (`slot_capacity` IDs: give it
  *                     the shard's row count and it can never be too small)
  *   exchange stream : (behind an event) the all-gather of the sizes and their copy to the host
- * and then finishes the queries handed in BEFORE this one: waits on the host for their sizes, enqueues their
- * send / recv group.  So the host's wait for query k's sizes falls under the scan of query k+1, and the
- * payload of query k moves under it too.  A slot may be reused after `ring` further calls; reuse waits on the
- * host for the earlier exchange.  pqps_exchange_result() finishes the slot if need be, waits for it and returns
+ * -- after it has finished an EARLIER query: waited on the host for that query's sizes and enqueued its send /
+ * recv group.  With a ring of 5 or more slots that is the query three calls back, whose scan ended while the two
+ * scans in flight ran: the call does not block and both scan lanes stay supplied (a ring of 4 finishes the query
+ * two calls back, a shorter one the previous query -- each step shorter makes the call wait for a scan that is
+ * still running).  A slot may be reused after `ring` further calls; reuse waits on the host for the earlier
+ * exchange.  pqps_exchange_result() finishes the slot if need be, waits for it and returns
  * the device pointer of the gathered ascending ID list (identical on every rank; valid until the slot is used
  * again), totals[0] = IDs gathered, totals[1] = IDs reported; PQPS_EOVERFLOW if a rank's own slot was too small. */
 typedef struct { char internal[128]; } pqps_rccl_id;     /* = ncclUniqueId */

@@ -1534,6 +1534,17 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     if (rc) return rc;
     rc = exchange_claim(x, slot);
     if (rc) return rc;
+    // First the payload of the query `hold` + 1 calls back.  With hold = 2 (a ring of 5 or more) nothing here waits
+    // for a scan that can still be running while the two lanes are busy: the sizes needed on the host belong to
+    // the scan three calls back, and the slot claimed above was released by a send / recv group that sits in the
+    // exchange stream behind the sizes of a scan at least three calls back -- so this query's scan reaches its lane
+    // while the lane's previous scan is still running.  A shorter ring holds less back (4: one query, 3 or
+    // fewer: none) and the call then waits for a running scan: the lane idles for a copy, a host wake-up and the
+    // enqueue (61 - 66 us per S1 query instead of 55, world of 1).  The order of RCCL calls follows from the call
+    // sequence alone, so it is the same on every rank.
+    const uint64_t hold = x->ring >= 5 ? 2 : (x->ring == 4 ? 1 : 0);
+    rc = exchange_finish_older(x, x->calls + 1 - hold);
+    if (rc) return rc;
     uint32_t *local = x->local + (uint64_t)slot * x->stride;
     uint64_t *sizes_dev = x->sizes_dev + (uint64_t)slot * x->world;
     uint64_t *sizes_host = x->sizes_host + (uint64_t)slot * x->world;
@@ -1576,9 +1587,7 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     HIP_TRY(hipEventRecord(x->sizes_done[slot], x->stream));
     x->state[slot] = kSlotSizesInFlight;
     x->issued[slot] = ++x->calls;
-    // ... and only now the payload of the queries before this one: the host waits for THEIR sizes while the
-    // device already has this query's scan to run.  (With a ring of one there is no query before.)
-    return exchange_finish_older(x, x->issued[slot]);
+    return PQPS_OK;
 }
 
 int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,

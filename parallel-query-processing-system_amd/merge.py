@@ -74,6 +74,7 @@ class IdMerger:
         self.merged = t.zeros(min(self.cap, 1 << 20), dtype=t.int32, device=device)   # grown to what a query needs
         self.totals = [0, 0]                                                      # merged, reported
         self._pending = False
+        self._issued = 0                  # serial number of the last begin() (callers finish mergers oldest first)
         self._sizes_pinned = None
         # every rank's capacity, once (shards differ by a row, so may the capacities): constructing a merger is
         # a collective step, like every later call
@@ -134,6 +135,8 @@ class IdMerger:
         else:
             self._sizes_host = self.sizes
         self._pending = True
+        IdMerger._serial = getattr(IdMerger, "_serial", 0) + 1
+        self._issued = IdMerger._serial
 
     def finish(self):
         """mpi:758-765 -- displacements on the host, then exactly count[r] IDs from every peer."""

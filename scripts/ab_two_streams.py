@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--prio", default="", help="priorities of the two streams, e.g. -1,0 (empty: default streams)")
     ap.add_argument("--copies", type=int, default=2)
+    ap.add_argument("--ring", type=int, default=6, help="result slots of the exchange")
+    ap.add_argument("--exchange", action="store_true", help="also time pqps_exchange_select with a world of one")
     ap.add_argument("--streams", type=int, default=2, help="contexts (streams) the queries go round")
     args = ap.parse_args()
     pq, _ = bench.load_pkg()
     L = pq.lib()
+    L.pqps_exchange_wait_ns.restype = C.c_uint64
     prios = args.prio.split(",") if args.prio else [None] * args.streams
     ctxs = []
     for p in prios:
@@ -64,6 +67,21 @@ def main():
         pq.check(L.pqps_qstream_sync(qs))
         dt = (time.perf_counter() - t0) / args.reps * 1e6
     print(f"[{args.query} rows={n:,}] pqps_qstream: {dt:7.1f} us per query", flush=True)
+    # ... and through the exchange with a world of one (the N > 1 path: sizes to the host, payload held back one query)
+    if args.exchange:
+        mg = bench.load_pkg()[1]
+        xch = mg.ShardExchange.open(pq, ctxs[0], None, None, 1, 0, n, ring=args.ring)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for k in range(args.reps):
+                pred, cols, nc, _ = bound[k % len(bound)]
+                xch.select(cols, nc, n, 0, C.byref(pred), k % args.ring, None)
+            xch.sync()
+            dt = (time.perf_counter() - t0) / args.reps * 1e6
+            waited = L.pqps_exchange_wait_ns(xch.h, 1) * 1e-3 / args.reps
+        print(f"[{args.query} rows={n:,}] pqps_exchange (world 1): {dt:7.1f} us per query, of which the host waited {waited:.1f} us "
+              f"(for a free slot or for sizes)", flush=True)
+        xch.close()
     for mode in ("one", "two"):
         for k in range(10):
             run(k, k % len(ctxs) if mode == "two" else 0)
