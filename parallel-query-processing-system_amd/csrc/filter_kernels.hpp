@@ -1088,7 +1088,7 @@ constexpr int kNearGroups = 6;     // supergroups in front whose group sums are 
 
 template <int NEAR>
 __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
-                                             uint32_t &cw, uint64_t &psum) {
+                                             uint32_t &cw, uint64_t &psum, bool final_word = false) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
     uint64_t own_super = 0;
     uint32_t left = 3u;
@@ -1117,7 +1117,7 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
         // likewise the supergroup's total, by the leader of its last group
         const uint32_t sum = wave_sum_u32(cw & kCountMask);
         if (lane == 0 && g % kSuperGroups == kSuperGroups - 1) st_sc1(a.ssum + g / kSuperGroups, tag | (own_super + (uint64_t)sum));
-    } else if (recovery) {
+    } else if (recovery || final_word) {
         if (lane == 0) st_sc1(a.status, 1u);                        // something never arrived: reported, never silent
     } else {
         if (lane == 0) {
@@ -1196,9 +1196,14 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
     const bool leader = !shared || wave == 0;
-    const uint64_t g = shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave;
+    // Gather (index mode): few groups, often dense -- a workgroup takes a QUARTER of a group (16 steps, 4 per wave),
+    // so that a narrow probe is spread over four times as many waves; role.index counts quarters.  Every quarter's
+    // leader settles the group for itself (and publishes its sum: the same value four times).
+    const uint32_t quarter = GATHER ? role.index % 4u : 0u;
+    const uint64_t g = GATHER ? (uint64_t)(role.index / 4u) : (shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave);
     if (g >= ex.groups) return;                                     // (the last quad of a table can be short)
     uint32_t c0 = shared ? wave * (kGroupSteps / kWaves) : 0u, c1 = shared ? c0 + kGroupSteps / kWaves : (uint32_t)kGroupSteps;
+    if constexpr (GATHER) { c0 = quarter * 16u + wave * 4u; c1 = c0 + 4u; }
     bool ok = false;
     uint32_t cnts = 0;
     uint64_t group_off = 0;
@@ -1218,10 +1223,12 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         // (the vector units are the bottleneck there), and the sums this leader publishes are what other groups wait
         // for (a lone u8 column at 100 M rows: last group settled 9.1 -> 3.8 us after the last tile).
         __builtin_amdgcn_s_setprio(3);
-        ok = settle_group<kNearGroups>(a, ex, g, lane, a.spin_limit, false, cw, psum);
+        // (gather: the whole grid is resident at once, so a wait can only fail if a tile never ran -- no second
+        // chance through the recovery pass there, the wait is long and its failure sets the status word)
+        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, psum, GATHER);
         __builtin_amdgcn_s_setprio(0);
         PQPS_STAMP_GROUP(a, g, 2);
-        ticket = ticket_draw(a, g, lane);                           // past its wait (a group given up is on record by now)
+        if constexpr (!GATHER) ticket = ticket_draw(a, g, lane);    // past its wait (a group given up is on record by now)
         if (ok) {
             cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
             group_off = (a.accumulate ? ld_sc1(a.base_slot) : 0ull) + psum;
@@ -1235,10 +1242,10 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         }
         __syncthreads();                                            // (waves that have left are not waited for)
         const uint32_t state = sh.state;
-        if (state == 2u) {                                          // few matches: the leader does all 64 steps
+        if (state == 2u) {                                          // few matches: the leader does all 64 steps (gather: its quarter)
             if (!leader) return;
-            c0 = 0;
-            c1 = kGroupSteps;
+            c0 = GATHER ? quarter * 16u : 0u;
+            c1 = GATHER ? c0 + 16u : (uint32_t)kGroupSteps;
         }
         ok = state != 0u;
         cnts = sh.counts[lane];
@@ -1247,7 +1254,8 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
     // the leader that was last to leave its wait looks after the groups others gave up on (if any)
-    if (leader && ticket_is_last(a, ticket, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
+    if constexpr (!GATHER)
+        if (leader && ticket_is_last(a, ticket, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
 }
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
@@ -1265,23 +1273,28 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
         // role again `layout` groups (tiles) further on.  (Scan tiles wait for nothing and the expanders come after
         // them in the grid, so the expanders' bounded waits always end.)
         const uint32_t layout = GATHER && ex.groups > a.grid_groups ? a.grid_groups : (uint32_t)ex.groups;
-        const Role role = fused_role<kGroupSteps / TS>(a, layout);
-        if (role.kind >= ROLE_EXPAND_QUAD) {
-            if constexpr (GATHER) {
-                Role r = role;                                      // (gather launches have no expanders among the tiles)
-                for (;;) {
+        Role role;
+        uint32_t layout_tiles;
+        if constexpr (GATHER) {
+            // gather grid: the tiles of `layout` groups, then four expander workgroups (quarters) per group
+            layout_tiles = layout * (uint32_t)(kGroupSteps / TS);
+            role.kind = uniform_u32(blockIdx.x < layout_tiles ? (uint32_t)ROLE_SCAN : (blockIdx.x - layout_tiles < 4u * layout ? (uint32_t)ROLE_EXPAND_GROUP : (uint32_t)ROLE_NONE));
+            role.index = uniform_u32(blockIdx.x < layout_tiles ? blockIdx.x : blockIdx.x - layout_tiles);
+            if (role.kind == ROLE_EXPAND_GROUP) {
+                for (Role r = role;;) {
                     expander_workgroup<GATHER, true>(a, sh, ex, r);
-                    r.index += layout;
-                    if (role.kind != ROLE_EXPAND_GROUP || r.index >= ex.groups) break;
+                    r.index += 4u * layout;
+                    if (r.index / 4u >= ex.groups) break;
                     __syncthreads();                                // the workgroup's LDS hand-over is free again
                 }
-            } else {
-                expander_workgroup<GATHER>(a, sh, ex, role);
+                return;
             }
-            return;
+        } else {
+            role = fused_role<kGroupSteps / TS>(a, layout);
+            layout_tiles = ((layout + 3u) / 4u) * 4u * (uint32_t)(kGroupSteps / TS);
+            if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<GATHER>(a, sh, ex, role); return; }
         }
         if (role.kind != ROLE_SCAN) return;
-        const uint32_t layout_tiles = ((layout + 3u) / 4u) * 4u * (uint32_t)(kGroupSteps / TS);
         for (uint64_t tile = role.index; tile * TS < ex.steps; tile += layout_tiles) {
             const uint64_t step = tile * TS + wv;
             const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, (uint32_t)tile, wv, lane);

@@ -562,7 +562,7 @@ uint32_t expand_spin_limit() {
 //   COUNT / FLAGS: the scan kernel + a one-workgroup reduction of the workgroup totals.
 //   ID output:     ONE launch -- scan tiles and, `lag` groups behind them in the grid, the expander
 //                  workgroups that turn match words into row IDs (filter_kernels.hpp).
-constexpr uint64_t kGatherGridGroups = 64;
+constexpr uint64_t kGatherGridGroups = 32;           // 512 tiles + 128 expander workgroups: resident all at once (4 workgroups per CU)
 
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
@@ -621,9 +621,11 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
     if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
     a.spin_limit = expand_spin_limit();
-    const uint64_t main_blocks = ((groups + 3) / 4) * (4ull * tiles_per_group + 1), lag = trailing_groups((uint32_t)groups, a.lag);
+    // gather: [tiles of `groups` groups][four expander workgroups per group]; scan: quads of tiles with their expander slot, then the trailing groups
+    const uint64_t main_blocks = gather ? groups * tiles_per_group : ((groups + 3) / 4) * (4ull * tiles_per_group + 1);
+    const uint64_t lag = gather ? 4 * groups : trailing_groups((uint32_t)groups, a.lag);
     if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
-    const uint64_t slack = gather ? 4 : 0;                        // gather: the device-side range decides; a smaller range can trail up to 3 more groups
+    const uint64_t slack = 0;
 #ifdef PQPS_STAMPS
     static uint64_t *stamp_buf = nullptr;
     static size_t stamp_words = 0;
