@@ -540,9 +540,7 @@ constexpr int kCtlShards = 64, kCtlStride = 32;                     // u32 words
 constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1) * kCtlStride;
 constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
 constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
-constexpr uint32_t kBlockIds = 192;         // FOUR steps with at most this many matches between them are expanded as one block
-                                            // (448 with a ring of 512: Q_A 90 -> 88 us, Q_B 107 -> 110, a lone u8 column 46 -> 47.5 at 100 M rows)
-constexpr uint32_t kStageRing = 256;        // >= max(kDirectIds, kBlockIds) + 63
+constexpr uint32_t kStageRing = 256;        // >= kDirectIds + 63
 constexpr uint32_t kSoloIds = 256;          // a trailing group with at most this many matches is expanded by its leader wave alone
 constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
@@ -727,10 +725,48 @@ __device__ __forceinline__ void sum_duty_finish(const EvalArgs &a, const SumDuty
     }
 }
 
+// A step with at most kListIds matches leaves them as a LIST: their row numbers inside the step (0 .. 1023, 16 bits
+// each) in ascending order, in the same 128 bytes a bit mask would take.  Turning bits into ranked row numbers is the
+// expensive part of the expansion (~70 vector instructions per step for a few-percent answer, and the expanders
+// behind the last tile have nothing to hide them under: 22 us of a 90 us Q_A at 100 M rows), whereas a scan tile's
+// vector units idle while it waits for memory.  What is left for the expander is a copy: list entry + first row
+// of the step -> ID.  Denser steps keep the bit mask (one 128-byte slot per step either way; which of the two
+// forms a slot holds follows from the step's count).
+//
+// Row order: bit p of lane l is row (p / RPL) * 64 * RPL + l * RPL + p % RPL, i.e. chunk by chunk (16 / RPL chunks),
+// inside a chunk lane by lane.  The per-lane counts of the <= 4 chunks travel through ONE wave scan as 8-bit fields
+// (no field exceeds 64), the chunks' bases come from the last lane's fields.
+constexpr uint32_t kListIds = 64;
+
+__device__ __forceinline__ void store_list(const EvalArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
+    const uint32_t rpl = 1u << rl, chunks = 16u >> rl;              // rl = 2, 3, 4: 4, 2, 1 chunks
+    uint32_t per = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++)
+        if (c < chunks) per |= (uint32_t)__popc((mbits >> (c * rpl)) & ((1u << rpl) - 1u)) << (8 * c);
+    const uint32_t incl = wave_incl_scan_u32(per);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t base = (tot << 8) + (tot << 16) + (tot << 24);   // field c: matches of the chunks before c
+    uint32_t at = base + incl - per;                                // field c: list slot of this lane's first match in chunk c
+    uint32_t m = mbits;
+    const uint32_t lane_rows = lane << rl;
+    while (m) {                                                     // set bits only: ascending rows inside a chunk
+        const uint32_t p = (uint32_t)__builtin_ctz(m);
+        m &= m - 1;
+        const uint32_t c = p >> rl, sh8 = 8u * c;
+        const uint32_t slot = (at >> sh8) & 0xFFu;
+        at += 1u << sh8;
+        stage[slot] = (uint16_t)((c << (6u + rl)) + lane_rows + (p & (rpl - 1u)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 16) st_sc1((uint64_t *)(a.masks + step * 64) + lane, ((const uint64_t *)stage)[lane]);   // (entries past the count: whatever)
+}
+
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
-    if (cnt) store_mask(a, step, mbits, lane);
+    if (cnt > kListIds) store_mask(a, step, mbits, lane);
+    else if (cnt) store_list(a, &sh.mask[threadIdx.x >> 6][0][0], step, mbits, rpl_log2, lane);
     if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << kRplShift);
 }
 
@@ -758,6 +794,17 @@ __device__ __forceinline__ void ring_flush(const EvalArgs &a, uint32_t *ring, Ou
     r.head = (r.head + n) & (kStageRing - 1);
     r.pending -= n;
     r.pos += n;
+}
+
+// Room for `need` more IDs behind the staged ones WITHOUT wrapping round the ring's end (need + 63 <= kStageRing):
+// if they would not fit, the < 64 staged IDs move to the front.  The rank loops can then walk a plain pointer --
+// one add per ID instead of mask + shift + add, in loops whose trip count is the fullest lane's.
+__device__ __forceinline__ void ring_reserve(uint32_t *ring, OutRing &r, uint32_t lane, uint32_t need) {
+    if (r.head + r.pending + need <= kStageRing) return;            // uniform
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the same wave wrote the ring
+    const uint32_t v = ring[(r.head + lane) & (kStageRing - 1)];
+    if (lane < r.pending) ring[lane] = v;                           // (one wave: its LDS reads and writes keep their order)
+    r.head = 0;
 }
 
 template <int RL>                                               // log2(RPL): 2, 3 or 4
@@ -845,25 +892,45 @@ __device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t b
     const uint32_t step_row0 = (uint32_t)(step * kStepRows);
     const uint32_t cnt = __popc(word);
     const uint32_t incl = wave_incl_scan_u32(cnt);
-    uint32_t slot = r.head + r.pending + (incl - cnt);
-    const uint32_t r0 = step_row0 + lane * 16u;
+    ring_reserve(ring, r, lane, count);
+    uint32_t *out = ring + (r.head + r.pending + (incl - cnt));
+    const uint32_t r0 = step_row0 + lane * 16u, r0b = r0 + a.id_base;
     while (word) {                                                  // set bits only, ascending rows
         const uint32_t j = (uint32_t)__builtin_ctz(word);
         word &= word - 1;
         // gather: the candidate number of the row (a set bit implies the row lies inside the probed range)
-        uint32_t id = r0 + j;
-        if constexpr (GATHER) id = a.cand[begin + r0 + j];
-        ring[slot & (kStageRing - 1)] = id + a.id_base;
-        slot++;
+        uint32_t id = r0b + j;
+        if constexpr (GATHER) id = a.cand[begin + r0 + j] + a.id_base;
+        *out++ = id;
     }
     r.pending += count;
     while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
 }
 
+// `slot` = the step's 128 bytes as parked in LDS: a row list (count <= kListIds, see store_list) or 16 match bits per lane.
 template <bool GATHER>
-__device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t m16, uint32_t rpl_log2,
+__device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
-    const uint32_t word = step_row_word(m16, rpl_log2, lane);
+    if (count <= kListIds) {
+        uint32_t id = 0;
+        if (lane < count) {
+            const uint32_t row = (uint32_t)(step * kStepRows) + slot[lane];
+            id = row;
+            if constexpr (GATHER) id = a.cand[begin + row];         // (a listed row lies inside the probed range)
+            id += a.id_base;
+        }
+        if (r.pending == 0) {                                       // uniform: nothing staged -> straight to the output, one store
+            if (lane < count && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = id;
+            r.pos += count;
+            return;
+        }
+        ring_reserve(ring, r, lane, count);
+        if (lane < count) ring[r.head + r.pending + lane] = id;
+        r.pending += count;
+        while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
+        return;
+    }
+    const uint32_t word = step_row_word(slot[lane], rpl_log2, lane);
     if (count <= kDirectIds) {
         expand_step_sparse<GATHER>(a, begin, step, word, count, lane, ring, r);
         return;
@@ -890,9 +957,12 @@ __device__ __forceinline__ bool word_valid(const EvalArgs &a, uint64_t w) { retu
 //                     gsums serve as well -- and the gsum of the earlier groups of its own supergroup.
 // `left`: bit 0 = own group still incomplete, bit 1 = front still unknown; a part that is settled is not read
 // again.  Returns the bits that are still open.
+// `watch` (set when the front is still open): the LAST of the sum words found missing -- sums appear roughly in
+// ascending order, so the caller can wait for that one word with one-load looks and come back for a full one
+// (which costs ~250 vector instructions) when it has appeared.
 template <int NEAR>
 __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
-                                               uint32_t &cw, uint64_t &psum, uint64_t &own_super) {
+                                               uint32_t &cw, uint64_t &psum, uint64_t &own_super, const uint64_t *&watch) {
     uint32_t now = 0;
     const uint64_t step = g * kGroupSteps + lane;
     uint32_t c = a.epoch << kEpochShift;
@@ -902,9 +972,10 @@ __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &
         const uint64_t far = sg > (uint64_t)NEAR ? sg - NEAR : 0;   // supergroups [0, far): by their words only
         bool ok = true;
         uint64_t acc = 0, mine = 0;
+        const uint64_t *missing = nullptr;                          // per lane: the last word this lane found missing
         for (uint64_t j = lane; j < far; j += 64) {
             const uint64_t w = ld_sc1(a.ssum + j);
-            ok = ok && word_valid(a, w);
+            if (!word_valid(a, w)) { ok = false; missing = a.ssum + j; }
             acc += w & kWordMask;
         }
         uint64_t ps = 0, pg[NEAR > 0 ? NEAR : 1];                   // supergroups [far, sg): word (lane k) or groups
@@ -914,26 +985,37 @@ __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &
             pg[k] = 0;
             if (far + k < sg) pg[k] = ld_sc1(a.gsum + (far + k) * kSuperGroups + lane);
         }
-        if (lane < g_in) {                                          // earlier groups of the own supergroup
-            const uint64_t w = ld_sc1(a.gsum + sg * kSuperGroups + lane);
-            ok = ok && word_valid(a, w);
-            mine = w & kWordMask;
-        }
-        bool all_ok = __all(ok);
         const uint64_t ps_ok = __ballot(far + lane < sg && word_valid(a, ps));
         if (far + lane < sg && word_valid(a, ps)) acc += ps & kWordMask;
+        bool near_ok = true;
 #pragma unroll
         for (int k = 0; k < NEAR; k++) {
             if (far + k < sg && !((ps_ok >> k) & 1ull)) {           // uniform
-                if (__all(word_valid(a, pg[k]))) acc += pg[k] & kWordMask;
-                else all_ok = false;
+                if (__all(word_valid(a, pg[k]))) {
+                    acc += pg[k] & kWordMask;
+                } else {
+                    near_ok = false;
+                    if (!word_valid(a, pg[k])) missing = a.gsum + (far + k) * kSuperGroups + lane;
+                }
             }
         }
-        if (all_ok) {
+        if (NEAR == 0 && __popcll(ps_ok) != (int)(sg - far)) {      // (the light look has no group sums to fall back on)
+            near_ok = false;
+            if (far + lane < sg && !word_valid(a, ps)) missing = a.ssum + far + lane;
+        }
+        if (lane < g_in) {                                          // earlier groups of the own supergroup
+            const uint64_t w = ld_sc1(a.gsum + sg * kSuperGroups + lane);
+            if (!word_valid(a, w)) { ok = false; missing = a.gsum + sg * kSuperGroups + lane; }
+            mine = w & kWordMask;
+        }
+        if (__all(ok) && near_ok) {
             own_super = wave_sum_u64(mine);
             psum = wave_sum_u64(acc) + own_super;
         } else {
             now |= 2u;
+            // one of the missing words, from the highest lane that has one (within an array that is the highest index)
+            const uint64_t who = __ballot(missing != nullptr);
+            if (who) watch = (const uint64_t *)(uintptr_t)readlane_u64((uint64_t)(uintptr_t)missing, 63 - (int)__builtin_clzll(who));
         }
     }
     if (left & 1u) {
@@ -942,65 +1024,35 @@ __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &
     return now;
 }
 
-// FOUR consecutive steps at once (4096 rows, at most kBlockIds matches between them): lane L takes rows
-// [64 L, 64 L + 64) of the block -- step L / 16, rows 64 (L % 16) .. of it -- and pulls their 64 match bits out
-// of the parked match words of that step: with RPL rows per lane and chunk they are the same RPL-bit field of
-// 64 / RPL neighbouring lanes' words, i.e. 8, 16 or 32 contiguous bytes of LDS.  One wave scan ranks all IDs of
-// the block.  (Per step the same work costs four times the instructions, and every one of them waits its turn
-// among the scan tiles' waves.)
-template <bool GATHER>
-__device__ __forceinline__ void expand_block(const EvalArgs &a, uint64_t begin, uint64_t step0, uint32_t rpl_log2, uint32_t total, uint32_t nb,
-                                             const uint16_t (*park)[64], uint32_t lane, uint32_t *ring, OutRing &r) {
-    const uint32_t s = lane >> 4, q = lane & 15u;
-    const uint16_t *row = park[s];
-    uint64_t w;
-    if (rpl_log2 == 4) {                                            // uniform: 16 rows per lane -> 4 lanes' words, in order
-        w = *(const uint64_t *)(row + 4u * q);
-    } else if (rpl_log2 == 3) {                                     // 8 rows per lane and chunk: byte q / 8 of 8 lanes' words
-        const uint4 d = *(const uint4 *)(row + 8u * (q & 7u));
-        const uint32_t sh8 = 8u * (q >> 3);
-        const uint32_t x[4] = {d.x, d.y, d.z, d.w};
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t two = ((x[i] >> sh8) & 0xFFu) | (((x[i] >> (16u + sh8)) & 0xFFu) << 8);     // lanes 2i, 2i+1
-            if (i < 2) lo |= two << (16 * i); else hi |= two << (16 * (i - 2));
-        }
-        w = (uint64_t)lo | ((uint64_t)hi << 32);
-    } else {                                                        // 4 rows per lane and chunk: nibble q / 4 of 16 lanes' words
-        const uint4 d0 = *(const uint4 *)(row + 16u * (q & 3u)), d1 = *(const uint4 *)(row + 16u * (q & 3u) + 8);
-        const uint32_t sh4 = 4u * (q >> 2);
-        const uint32_t x[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t two = ((x[i] >> sh4) & 0xFu) | (((x[i] >> (16u + sh4)) & 0xFu) << 4);        // lanes 2i, 2i+1
-            if (i < 4) lo |= two << (8 * i); else hi |= two << (8 * (i - 4));
-        }
-        w = (uint64_t)lo | ((uint64_t)hi << 32);
+// A wave of an expander workgroup that has nothing to do while its leader waits for the sums in front of the group
+// asks for the match words of its OWN 16 steps [c0, c0 + 16) already -- if their count words are all there (one
+// look, no waiting: a hint).  The words land in the wave's LDS slice, slot = step - c0, while the leader settles;
+// expand_range then finds them there instead of paying a memory latency after the barrier (2.8 us of the 7 us a
+// trailing group of Q_A took from settled to done).  Returns the steps requested (bits 0 .. 15) | 1 << 16, or 0.
+__device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
+                                                       uint32_t c0, uint32_t park) {
+    typedef __attribute__((address_space(1))) const void global_cvoid;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const uint64_t step = g * kGroupSteps + c0 + (lane & 15u);
+    uint32_t c = a.epoch << kEpochShift;
+    if (lane < 16 && step < ex.steps) c = ld_sc1(a.counts + step);
+    if (!__all((c >> kEpochShift) == a.epoch)) return 0u;            // uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: the payload loads stay behind the look
+    const uint32_t bits = uniform_u32((uint32_t)__ballot(lane < 16 && (c & kCountMask) != 0) & 0xFFFFu);
+    const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + c0) * 64) + lane;
+    for (uint32_t rest = bits; rest; rest &= rest - 1) {            // uniform
+        const uint32_t k = (uint32_t)__builtin_ctz(rest);
+        if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
     }
-    if (!((nb >> s) & 1u)) w = 0;                                   // an empty step: its slot was not filled
-    const uint32_t cnt = (uint32_t)__popcll(w);
-    const uint32_t incl = wave_incl_scan_u32(cnt);
-    uint32_t slot = r.head + r.pending + (incl - cnt);
-    const uint32_t r0 = (uint32_t)(step0 * kStepRows) + lane * 64u;
-    while (w) {                                                     // set bits only, ascending rows
-        const uint32_t j = (uint32_t)__builtin_ctzll(w);
-        w &= w - 1;
-        uint32_t id = r0 + j;
-        if constexpr (GATHER) id = a.cand[begin + r0 + j];
-        ring[slot & (kStageRing - 1)] = id + a.id_base;
-        slot++;
-    }
-    r.pending += total;
-    while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
+    return bits | (1u << 16);
 }
 
 // The calling wave turns the match words of steps [c0, c1) of group g (both multiples of 16) into row IDs
 // (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
+// `pre` = what prefetch_own_steps returned for [c0, c0 + 16) (0: nothing is on its way).
 template <bool GATHER>
 __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
-                                             uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off) {
+                                             uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0) {
     const uint32_t my_cnt = cw & kCountMask;
     const uint32_t incl = wave_incl_scan_u32(my_cnt);
     const uint64_t my_off = group_off + (incl - my_cnt);
@@ -1008,9 +1060,6 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     const uint64_t span = (c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
     const uint64_t nonempty = __ballot(my_cnt != 0) & span;         // non-empty steps of the range (wave-uniform)
     if (!nonempty) return;
-    // matches of the block of 4 steps a lane's step belongs to (DPP quad sums)
-    uint32_t quad = my_cnt + dpp_or_zero<0xb1>(my_cnt);
-    quad += dpp_or_zero<0x4e>(quad);
     const uint32_t rpl_log2 = ((uint32_t)__builtin_amdgcn_readlane((int)cw, (int)__builtin_ctzll(nonempty)) >> kRplShift) & 7u;   // one per query
     uint32_t *ring = sh.stage[park];
     OutRing r;
@@ -1019,22 +1068,26 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     r.pos = readlane_u64(my_off, (int)__builtin_ctzll(nonempty));   // the range's IDs form one run of the output
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
+    // the prefetched words serve if they are exactly what this range needs (same 16 steps, same non-empty ones)
+    const bool have = pre != 0 && c1 == c0 + 16u && (uint32_t)(nonempty >> c0) == (pre & 0xFFFFu);    // uniform
     if (__popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
         // At most 16 non-empty steps in the whole range (a sparse answer): ONE round of loads fetches all their
-        // match words, slot k of the LDS slice = the k-th of them, and they are expanded step by step.
+        // match words, slot k of the LDS slice = the k-th of them (prefetched: slot = step - c0), and they are
+        // expanded step by step.
         const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
         uint32_t k = 0;
-        for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
-            const uint32_t st = (uint32_t)__builtin_ctzll(rest);
-            if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
-        }
+        if (!have)
+            for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
+                const uint32_t st = (uint32_t)__builtin_ctzll(rest);
+                if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler does not count LDS-DMA as a write to LDS)
         if (c0 == 0) PQPS_STAMP_GROUP(a, g, 5);
         k = 0;
         for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {
             const uint32_t st = (uint32_t)__builtin_ctzll(rest);
             const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
-            expand_step<GATHER>(a, ex.begin, g * kGroupSteps + st, sh.mask[park][k][lane], rpl_log2, cwi & kCountMask, lane, ring, r);
+            expand_step<GATHER>(a, ex.begin, g * kGroupSteps + st, sh.mask[park][have ? st - c0 : k], rpl_log2, cwi & kCountMask, lane, ring, r);
         }
         if (r.pending) ring_flush(a, ring, r, lane, r.pending);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1055,21 +1108,10 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not count LDS-DMA as a write to LDS)
         }
-        for (uint32_t bb = 0; bb < 4; bb++) {                       // blocks of 4 steps
-            const uint32_t nb = (bits >> (4 * bb)) & 0xFu;
-            if (!nb) continue;
-            const uint32_t sidx0 = w0 + 4 * bb;
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
-            if (total <= kBlockIds) {
-                expand_block<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, rpl_log2, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
-            } else {
-                for (uint32_t i = 0; i < 4; i++) {
-                    if (!((nb >> i) & 1u)) continue;
-                    const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i));
-                    expand_step<GATHER>(a, ex.begin, g * kGroupSteps + sidx0 + i, sh.mask[park][4 * bb + i][lane], rpl_log2, cwi & kCountMask,
-                                        lane, ring, r);
-                }
-            }
+        for (uint32_t rest = bits; rest; rest &= rest - 1) {        // uniform
+            const uint32_t k = (uint32_t)__builtin_ctz(rest);
+            const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(w0 + k));
+            expand_step<GATHER>(a, ex.begin, g * kGroupSteps + w0 + k, sh.mask[park][k], rpl_log2, cwi & kCountMask, lane, ring, r);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the slice is filled again
     }
@@ -1098,7 +1140,9 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
     // missing supergroup words are read as well.
     bool light = g + a.sum_lag + (uint64_t)(NEAR + 1) * kSuperGroups < ex.groups;
     for (uint32_t spins = 0;; spins++) {
-        left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super) : poll_group<NEAR>(a, ex, g, lane, left, cw, psum, own_super);
+        const uint64_t *watch = nullptr;
+        left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super, watch)
+                     : poll_group<NEAR>(a, ex, g, lane, left, cw, psum, own_super, watch);
         light = false;
         PQPS_STAMP_VALUE(a, g, 4, (uint64_t)spins + 1);
         if (!(left & 1u) && !sum_out) {
@@ -1110,6 +1154,9 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
         }
         if (left == 0 || spins >= limit) break;
         __builtin_amdgcn_s_sleep(16);
+        // the front is what is missing: cheap looks at one of the missing words until it has appeared
+        if (left == 2u && watch != nullptr)
+            while (spins < limit && !word_valid(a, ld_sc1(watch))) { __builtin_amdgcn_s_sleep(8); spins++; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: payload loads stay behind the polls
     const bool ok = left == 0;
@@ -1148,7 +1195,8 @@ __device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared 
             alive = false;
 #pragma unroll 1
             for (uint32_t spins = 0; spins < kRecoverSpins; spins++) {
-                if (!(poll_group<0>(a, ex, gg, lane, 1u, cw, unused, unused) & 1u)) { alive = true; break; }
+                const uint64_t *nowatch = nullptr;
+                if (!(poll_group<0>(a, ex, gg, lane, 1u, cw, unused, unused, nowatch) & 1u)) { alive = true; break; }
                 __builtin_amdgcn_s_sleep(16);
             }
             const uint32_t sum = wave_sum_u32(cw & kCountMask);
@@ -1215,6 +1263,9 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         if (word_valid(a, w) && (w & kWordMask) <= kSoloIds) return;        // uniform
     }
     uint32_t ticket = 0;
+    uint32_t pre = 0;
+    if constexpr (!GATHER)                                          // (a gather workgroup's waves take 4 steps each)
+        if (shared) pre = prefetch_own_steps(a, sh, ex, g, lane, c0, wave);
     if (leader) {
         uint32_t cw = 0;
         uint64_t psum = 0;
@@ -1251,7 +1302,7 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         cnts = sh.counts[lane];
         group_off = sh.group_off;
     }
-    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off);
+    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
     // the leader that was last to leave its wait looks after the groups others gave up on (if any)
     if constexpr (!GATHER)

@@ -537,7 +537,11 @@ uint32_t expand_lag_base(const pqps_ctx *ctx, uint32_t tiles_per_group) {
 uint32_t expand_sum_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
     static const char *env = getenv("PQPS_SUM_LAG");                // huge: no tile sums anything up (tests: every expander does it itself)
     if (env) return (uint32_t)strtoul(env, nullptr, 10);
-    return expand_lag_base(ctx, tiles_per_group);
+    // Twice the groups in flight: a tile that looks `base` groups back finds some straggler of those 16 tiles still
+    // running more often than not (stamps: expanders needed 3.2 looks on average and 5.6 us from start to settled
+    // with `base`, 1.5 looks and 2.9 us with twice that; S1 58.0 -> 57.5 us, Q_A 82.5 -> 80.4, Q_B 107.8 -> 103.8 at
+    // 100 M rows).  The groups behind that horizon at the end of the table are summed up by their own expanders.
+    return 2u * expand_lag_base(ctx, tiles_per_group);
 }
 
 // Expanders among the scan tiles hide their work under the scan, but hold wave slots the scan could use and leave
@@ -550,7 +554,9 @@ uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group, uint64_t grou
     static const char *env = getenv("PQPS_EXPAND_LAG");
     if (env) return (uint32_t)strtoul(env, nullptr, 10);
     if (groups < kInterleaveFromGroups) return 0x7FFFFFFFu;         // all behind the last tile
-    return 2u * expand_sum_lag(ctx, tiles_per_group);
+    // behind the sums it needs: at 1 G rows (sum lag / expander lag in groups) 150 / 300: Q_A 686 us, Q_B 918;
+    // 300 / 600: 699, 938; 300 / 450: 669, 903
+    return expand_sum_lag(ctx, tiles_per_group) + expand_lag_base(ctx, tiles_per_group);
 }
 
 uint32_t expand_spin_limit() {
