@@ -725,21 +725,31 @@ __device__ __forceinline__ void sum_duty_finish(const EvalArgs &a, const SumDuty
     }
 }
 
-// A step with at most kListIds matches leaves them as a LIST: their row numbers inside the step (0 .. 1023, 16 bits
-// each) in ascending order, in the same 128 bytes a bit mask would take.  Turning bits into ranked row numbers is the
-// expensive part of the expansion (~70 vector instructions per step for a few-percent answer, and the expanders
-// behind the last tile have nothing to hide them under: 22 us of a 90 us Q_A at 100 M rows), whereas a scan tile's
-// vector units idle while it waits for memory.  What is left for the expander is a copy: list entry + first row
-// of the step -> ID.  Denser steps keep the bit mask (one 128-byte slot per step either way; which of the two
-// forms a slot holds follows from the step's count).
+// A step with at most kListIds matches leaves them as a LIST: their row numbers inside the step (0 .. 1023, 10 bits
+// each, packed) in ascending order, in the same 128 bytes a bit mask would take.  Turning bits into ranked row numbers
+// is the expensive part of the expansion (~70 vector instructions per step for a few-percent answer, and the
+// expanders behind the last tile have nothing to hide them under: 22 us of a 90 us Q_A at 100 M rows), whereas a
+// scan tile's vector units idle while it waits for memory.  What is left for the expander is a copy: list entry +
+// first row of the step -> ID.  Denser steps keep the bit mask (one 128-byte slot per step either way; which of the
+// two forms a slot holds follows from the step's count).
 //
 // Row order: bit p of lane l is row (p / RPL) * 64 * RPL + l * RPL + p % RPL, i.e. chunk by chunk (16 / RPL chunks),
 // inside a chunk lane by lane.  The per-lane counts of the <= 4 chunks travel through ONE wave scan as 8-bit fields
-// (no field exceeds 64), the chunks' bases come from the last lane's fields.
-constexpr uint32_t kListIds = 64;
+// (no field exceeds 102), the chunks' bases come from the last lane's fields.
+constexpr uint32_t kListIds = 102;          // 1024 bits / 10
+// ... unless the widest predicate column is one byte wide (RPL = 16): a step is then 1 KB of input, the scan tile
+// has ~100 instruction slots per step to keep up with HBM and none to spare (a lone u8 column with lists: 47.5 -> 54.3 us).
+__device__ __forceinline__ uint32_t list_limit(uint32_t rpl_log2) { return rpl_log2 >= 4u ? 0u : kListIds; }
 
-__device__ __forceinline__ void store_list(const EvalArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
+__device__ __forceinline__ uint32_t list_entry(const uint32_t *slot32, uint32_t i) {
+    const uint32_t bit = 10u * i, w = bit >> 5, sft = bit & 31u;
+    const uint64_t two = (uint64_t)slot32[w] | ((uint64_t)slot32[w < 31u ? w + 1u : 31u] << 32);   // (word 31 never needs a second one)
+    return (uint32_t)(two >> sft) & 0x3FFu;
+}
+
+__device__ __forceinline__ void store_list(const EvalArgs &a, uint32_t *stage32, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
     const uint32_t rpl = 1u << rl, chunks = 16u >> rl;              // rl = 2, 3, 4: 4, 2, 1 chunks
+    if (lane < 32) stage32[lane] = 0u;
     uint32_t per = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++)
@@ -754,19 +764,22 @@ __device__ __forceinline__ void store_list(const EvalArgs &a, uint16_t *stage, u
         const uint32_t p = (uint32_t)__builtin_ctz(m);
         m &= m - 1;
         const uint32_t c = p >> rl, sh8 = 8u * c;
-        const uint32_t slot = (at >> sh8) & 0xFFu;
+        const uint32_t bit = 10u * ((at >> sh8) & 0xFFu), w = bit >> 5, sft = bit & 31u;
         at += 1u << sh8;
-        stage[slot] = (uint16_t)((c << (6u + rl)) + lane_rows + (p & (rpl - 1u)));
+        const uint32_t row = (c << (6u + rl)) + lane_rows + (p & (rpl - 1u));
+        // (entries of different lanes share words: LDS atomics)
+        __hip_atomic_fetch_or(stage32 + w, row << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sft > 22u) __hip_atomic_fetch_or(stage32 + w + 1, row >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < 16) st_sc1((uint64_t *)(a.masks + step * 64) + lane, ((const uint64_t *)stage)[lane]);   // (entries past the count: whatever)
+    if (lane < 16) st_sc1((uint64_t *)(a.masks + step * 64) + lane, ((const uint64_t *)stage32)[lane]);
 }
 
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
-    if (cnt > kListIds) store_mask(a, step, mbits, lane);
-    else if (cnt) store_list(a, &sh.mask[threadIdx.x >> 6][0][0], step, mbits, rpl_log2, lane);
+    if (cnt > list_limit(rpl_log2)) store_mask(a, step, mbits, lane);
+    else if (cnt) store_list(a, (uint32_t *)&sh.mask[threadIdx.x >> 6][0][0], step, mbits, rpl_log2, lane);
     if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << kRplShift);
 }
 
@@ -911,23 +924,27 @@ __device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t b
 template <bool GATHER>
 __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
-    if (count <= kListIds) {
-        uint32_t id = 0;
-        if (lane < count) {
-            const uint32_t row = (uint32_t)(step * kStepRows) + slot[lane];
-            id = row;
-            if constexpr (GATHER) id = a.cand[begin + row];         // (a listed row lies inside the probed range)
-            id += a.id_base;
+    if (count <= list_limit(rpl_log2)) {
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < count; i0 += 64) {               // uniform: one round, two for more than 64 entries
+            const uint32_t n = count - i0 < 64u ? count - i0 : 64u;
+            uint32_t id = 0;
+            if (lane < n) {
+                const uint32_t row = (uint32_t)(step * kStepRows) + list_entry((const uint32_t *)slot, i0 + lane);
+                id = row;
+                if constexpr (GATHER) id = a.cand[begin + row];     // (a listed row lies inside the probed range)
+                id += a.id_base;
+            }
+            if (r.pending == 0) {                                   // uniform: nothing staged -> straight to the output, one store
+                if (lane < n && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = id;
+                r.pos += n;
+                continue;
+            }
+            ring_reserve(ring, r, lane, n);
+            if (lane < n) ring[r.head + r.pending + lane] = id;
+            r.pending += n;
+            while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
         }
-        if (r.pending == 0) {                                       // uniform: nothing staged -> straight to the output, one store
-            if (lane < count && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = id;
-            r.pos += count;
-            return;
-        }
-        ring_reserve(ring, r, lane, count);
-        if (lane < count) ring[r.head + r.pending + lane] = id;
-        r.pending += count;
-        while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
         return;
     }
     const uint32_t word = step_row_word(slot[lane], rpl_log2, lane);
