@@ -232,9 +232,10 @@ int pqps_merge_slots(pqps_ctx *ctx, const uint32_t *slots, uint32_t world, uint6
  * what that stream holds at that moment.  Results are complete after pqps_qstream_sync() (or a device
  * synchronise); the caller keeps a ring of `depth` out_ids / out_count pairs, the call for query k uses pair
  * k % depth and blocks on the host only until query k - depth has finished.
- * The two streams must sit on different hardware queues of the runtime: the library asks for
- * GPU_MAX_HW_QUEUES=8 when it is loaded before the HIP runtime starts; a host that starts HIP first (e.g.
- * torch) sets that variable itself. */
+ * The two streams must sit on different hardware queues of the runtime (two streams that share one run their
+ * launches one after the other): they are created at the highest stream priority, both the same -- the runtime
+ * keeps a pool of hardware queues per priority, so they get two queues of their own however many streams the
+ * rest of the process has created. */
 typedef struct pqps_qstream pqps_qstream;
 int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out);
 int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,

@@ -682,7 +682,24 @@ int pqps_device_count(void) {
     return n;
 }
 
-int pqps_ctx_create(int device, pqps_ctx **out) {
+}  // extern "C"
+
+namespace { int create_ctx(int device, bool lane, pqps_ctx **out); }
+
+extern "C" {
+
+int pqps_ctx_create(int device, pqps_ctx **out) { return create_ctx(device, false, out); }
+
+}  // extern "C"
+
+namespace {
+
+// `lane`: the context is one of the two scan lanes of a query stream / an exchange.  Its HIP stream is created at
+// the highest priority: the runtime keeps a separate pool of hardware queues per priority, so the two lanes get
+// two queues of their own whatever else the process has created (torch alone creates dozens of streams; two lanes
+// that end up on one hardware queue run their scans one after the other and the overlap is gone).  Both lanes
+// have the SAME priority: neither is favoured.
+int create_ctx(int device, bool lane, pqps_ctx **out) {
     if (!out) return fail(PQPS_EINVAL, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -710,10 +727,11 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
     ctx->stop_is_eval = nullptr;
     hipError_t se;
-    if (const char *prio = getenv("PQPS_STREAM_PRIORITY")) {     // experiments: the context's own stream at a given priority
+    const char *prio = getenv("PQPS_STREAM_PRIORITY");           // experiments: the context's own stream at a given priority
+    if (prio || lane) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        int p = atoi(prio);
+        int p = prio ? atoi(prio) : greatest;
         if (p < greatest) p = greatest;
         if (p > least) p = least;
         se = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, p);
@@ -732,6 +750,10 @@ int pqps_ctx_create(int device, pqps_ctx **out) {
     *out = ctx;
     return PQPS_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
@@ -1395,7 +1417,7 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     x->child = new pqps_ctx *[kExchangeLanes](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
     X_TRY(hipEventCreateWithFlags(&x->joined, hipEventDisableTiming));
     for (uint32_t i = 0; i < kExchangeLanes; i++)
-        if (pqps_ctx_create(ctx->device, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
+        if (create_ctx(ctx->device, true, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
     x->merged = new uint32_t *[ring](); x->merged_cap = new uint64_t[ring](); x->totals_host = new uint64_t[2 * (size_t)ring]();
     x->caps = new uint64_t[world]();
     for (uint32_t i = 0; i < ring; i++) {
@@ -1719,7 +1741,7 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->joined, hipEventDisableTiming);
     for (uint32_t i = 0; i < depth && e == hipSuccess; i++) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
     for (uint32_t i = 0; i < q->lanes && e == hipSuccess; i++)
-        if (pqps_ctx_create(ctx->device, &q->child[i]) != PQPS_OK) { pqps_qstream_destroy(q); return PQPS_EHIP; }
+        if (create_ctx(ctx->device, true, &q->child[i]) != PQPS_OK) { pqps_qstream_destroy(q); return PQPS_EHIP; }
     if (e != hipSuccess) { pqps_qstream_destroy(q); return fail(PQPS_EHIP, "query stream: %s", hipGetErrorString(e)); }
     *out = q;
     return PQPS_OK;
