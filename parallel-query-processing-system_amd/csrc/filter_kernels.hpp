@@ -1064,12 +1064,46 @@ __device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedS
     return bits | (1u << 16);
 }
 
+// The LEADER's look ahead: it reads all 64 count words anyway.  A group with few matches (<= kSoloIds: the leader
+// will expand it alone) and at most 16 non-empty steps gets those steps' slots requested in the packed order the
+// sparse branch of expand_range uses (slot k = the k-th non-empty step) -> returns 2 << 16 and the steps in `mask`;
+// otherwise the leader's own quarter as in prefetch_own_steps.
+__device__ __forceinline__ uint32_t prefetch_as_leader(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
+                                                       uint32_t park, uint64_t &mask) {
+    typedef __attribute__((address_space(1))) const void global_cvoid;
+    typedef __attribute__((address_space(3))) void lds_void;
+    mask = 0;
+    const uint64_t step = g * kGroupSteps + lane;
+    uint32_t c = a.epoch << kEpochShift;
+    if (step < ex.steps) c = ld_sc1(a.counts + step);
+    if (!__all((c >> kEpochShift) == a.epoch)) return 0u;            // uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint64_t nonempty = __ballot((c & kCountMask) != 0);
+    const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
+    if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
+        uint32_t k = 0;
+        for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
+            const uint32_t st = (uint32_t)__builtin_ctzll(rest);
+            if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+        }
+        mask = nonempty;
+        return 2u << 16;
+    }
+    const uint32_t bits = uniform_u32((uint32_t)nonempty & 0xFFFFu);
+    for (uint32_t rest = bits; rest; rest &= rest - 1) {            // uniform
+        const uint32_t k = (uint32_t)__builtin_ctz(rest);
+        if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+    }
+    return bits | (1u << 16);
+}
+
 // The calling wave turns the match words of steps [c0, c1) of group g (both multiples of 16) into row IDs
 // (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
 // `pre` = what prefetch_own_steps returned for [c0, c0 + 16) (0: nothing is on its way).
 template <bool GATHER>
 __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
-                                             uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0) {
+                                             uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0,
+                                             uint64_t pre_mask = 0) {
     const uint32_t my_cnt = cw & kCountMask;
     const uint32_t incl = wave_incl_scan_u32(my_cnt);
     const uint64_t my_off = group_off + (incl - my_cnt);
@@ -1086,14 +1120,15 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
     // the prefetched words serve if they are exactly what this range needs (same 16 steps, same non-empty ones)
-    const bool have = pre != 0 && c1 == c0 + 16u && (uint32_t)(nonempty >> c0) == (pre & 0xFFFFu);    // uniform
+    const bool have = (pre >> 16) == 1u && c1 == c0 + 16u && (uint32_t)(nonempty >> c0) == (pre & 0xFFFFu);    // uniform
+    const bool have_packed = (pre >> 16) == 2u && nonempty == pre_mask;     // the leader's look ahead for a group it expands alone
     if (__popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
         // At most 16 non-empty steps in the whole range (a sparse answer): ONE round of loads fetches all their
         // match words, slot k of the LDS slice = the k-th of them (prefetched: slot = step - c0), and they are
         // expanded step by step.
         const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
         uint32_t k = 0;
-        if (!have)
+        if (!have && !have_packed)
             for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
                 const uint32_t st = (uint32_t)__builtin_ctzll(rest);
                 if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
@@ -1281,8 +1316,10 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     }
     uint32_t ticket = 0;
     uint32_t pre = 0;
-    if constexpr (!GATHER)                                          // (a gather workgroup's waves take 4 steps each)
-        if (shared) pre = prefetch_own_steps(a, sh, ex, g, lane, c0, wave);
+    uint64_t pre_mask = 0;
+    if constexpr (!GATHER) {                                        // (a gather workgroup's waves take 4 steps each)
+        if (shared) pre = leader ? prefetch_as_leader(a, sh, ex, g, lane, wave, pre_mask) : prefetch_own_steps(a, sh, ex, g, lane, c0, wave);
+    }
     if (leader) {
         uint32_t cw = 0;
         uint64_t psum = 0;
@@ -1319,7 +1356,7 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         cnts = sh.counts[lane];
         group_off = sh.group_off;
     }
-    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre);
+    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
     // the leader that was last to leave its wait looks after the groups others gave up on (if any)
     if constexpr (!GATHER)
