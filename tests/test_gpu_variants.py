@@ -6,8 +6,8 @@ small sizes through the shim's switches -- each in its own process, because the 
     so that expanders really are early and wait for their tiles, sums and neighbours
   * the recovery pass: every expander gives up at its first look (spin limit 0), no tile does sum duty -- the
     last expander publishes every sum and expands every group on its own
-  * a dense answer at > 600 M rows (default placement among the tiles, block and 64-row expansion paths):
-    head and tail of the ID list bit-exact against the host twin, the middle by count and order
+  * a dense answer at > 600 M rows (default placement among the tiles; row lists, ranked bit masks and the 64-row
+    expansion path): head and tail of the ID list bit-exact against the host twin, the middle by count and order
 """
 import ctypes as C
 import os
