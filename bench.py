@@ -154,7 +154,7 @@ def main():
                     help="N>1 exchange step: 'rccl' = the shim calls ncclAllGather itself (one host call per query); "
                          "'torch' = torch.distributed collectives from Python (also the gloo rehearsal path)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="N=1: every query's K1, K2, K3 on one stream (no overlap of K2/K3 with the next query's K1)")
+                    help="N=1: one query at a time on one stream (no second query in flight)")
     ap.add_argument("--force-merge", action="store_true",
                     help="N=1 rehearsal: run the N>1 exchange step (RCCL all-gather + merge, second stream) with a world of 1")
     args = ap.parse_args()

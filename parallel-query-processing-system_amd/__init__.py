@@ -426,7 +426,7 @@ class Context:
         check(lib().pqps_ctx_set_timing(self.h, 1 if on else 0))
 
     def kernel_time(self):
-        """-> (ms in the evaluate kernel K1, ms in K1..K3, launches) summed since the last call."""
+        """-> (ms in the scan kernel, ms in the whole query, launches) summed since the last call (an ID query is one launch: both equal)."""
         ev, tot, k = C.c_double(), C.c_double(), C.c_int()
         check(lib().pqps_ctx_kernel_time(self.h, C.byref(ev), C.byref(tot), C.byref(k)))
         return ev.value, tot.value, k.value

@@ -3,7 +3,7 @@
 // The ONLY translation unit compiled by hipcc (filter_kernels.hpp is included here).
 // No CUDA-compat headers, no dual paths: wave = 64 lanes, written for CDNA4 directly.
 // No MFMA anywhere: this is integer compare + compaction, bound by HBM reads.
-// The filter pipeline (K1 eval -> K2 scan -> K3 expand) is described in filter_kernels.hpp.
+// The filter launch (scan tiles + expanders in one grid) is described in filter_kernels.hpp.
 
 #include <cmath>
 #include <cstdarg>
