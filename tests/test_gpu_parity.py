@@ -435,6 +435,32 @@ def test_bench_exchange_path_runs_on_one_gpu():
         assert ("shim-driven" if mode == "rccl" else "torch.distributed") in d["config"]["parallelism"]
 
 
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--query", "Q_A"]), (2, ["--mode", "count"])])
+def test_bench_with_several_ranks_sharing_the_gpu(ranks, extra):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), with the ranks sharing
+    this box's one GPU and gloo as the transport (RCCL refuses two ranks on one device): row-range shards, the sizes-first
+    exchange through merge.IdMerger with queries in flight, the COUNT all-reduce, and bench.py's own verification of the
+    gathered result on EVERY rank (it asserts).  One JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(q.ROOT / "bench.py"),
+                        "--gpus", str(ranks), "--backend", "gloo", "--rows", "2000003", "--steps", "12", "--warmup", "3",
+                        "--no-extras", "--no-cpu-baseline", *extra],
+                       capture_output=True, text=True, timeout=900, cwd=str(q.ROOT))
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["steps"] == 12 and d["config"]["rows_total"] == 2000003 * ranks
+    assert d["config"]["matches_total"] > 0 and d["scaling"] == "weak"
+
+
 def test_flags_mode(ctx):
     n = 70_001
     dev = pq.SyntheticTable(ctx, n, seed=9)
