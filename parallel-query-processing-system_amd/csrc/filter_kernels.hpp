@@ -540,7 +540,8 @@ constexpr int kCtlShards = 64, kCtlStride = 32;                     // u32 words
 constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1) * kCtlStride;
 constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
 constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
-constexpr uint32_t kStageRing = 256;        // >= kDirectIds + 63
+constexpr uint32_t kBlockIds = 448;         // 1-byte columns: FOUR steps with at most this many matches between them are ranked as one block
+constexpr uint32_t kStageRing = 512;        // >= max(kDirectIds, kBlockIds) + 63
 constexpr uint32_t kSoloIds = 256;          // a trailing group with at most this many matches is expanded by its leader wave alone
 constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
@@ -920,6 +921,37 @@ __device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t b
     while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
 }
 
+// One-byte-wide predicates (RPL = 16: no row lists, and the match words are in row order as they are): FOUR
+// consecutive steps at once, lane L takes rows [64 L, 64 L + 64) of the block -- 8 contiguous bytes of the parked
+// words of step L / 16 -- one wave scan ranks all IDs of the block, and the rank loop's trip count is that of the
+// fullest 64-row lane instead of four times that of the fullest 16-row lane.
+template <bool GATHER>
+__device__ __forceinline__ void expand_block16(const EvalArgs &a, uint64_t begin, uint64_t step0, uint32_t total, uint32_t nb,
+                                               const uint16_t (*park)[64], uint32_t lane, uint32_t *ring, OutRing &r) {
+    const uint32_t st = lane >> 4, q = lane & 15u;
+    uint64_t w = *(const uint64_t *)(park[st] + 4u * q);
+    if (!((nb >> st) & 1u)) w = 0;                                  // an empty step: its slot was not filled
+    const uint32_t cnt = (uint32_t)__popcll(w);
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    ring_reserve(ring, r, lane, total);
+    uint32_t *out = ring + (r.head + r.pending + (incl - cnt));
+    const uint32_t r0 = (uint32_t)(step0 * kStepRows) + lane * 64u, r0b = r0 + a.id_base;
+    uint32_t half = (uint32_t)w;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        while (half) {                                              // set bits only, ascending rows
+            const uint32_t j = (uint32_t)__builtin_ctz(half) + 32u * h;
+            half &= half - 1;
+            uint32_t id = r0b + j;
+            if constexpr (GATHER) id = a.cand[begin + r0 + j] + a.id_base;
+            *out++ = id;
+        }
+        half = (uint32_t)(w >> 32);
+    }
+    r.pending += total;
+    while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
+}
+
 // `slot` = the step's 128 bytes as parked in LDS: a row list (count <= kListIds, see store_list) or 16 match bits per lane.
 template <bool GATHER>
 __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
@@ -1122,7 +1154,10 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     // the prefetched words serve if they are exactly what this range needs (same 16 steps, same non-empty ones)
     const bool have = (pre >> 16) == 1u && c1 == c0 + 16u && (uint32_t)(nonempty >> c0) == (pre & 0xFFFFu);    // uniform
     const bool have_packed = (pre >> 16) == 2u && nonempty == pre_mask;     // the leader's look ahead for a group it expands alone
-    if (__popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
+    // matches of the block of 4 steps a lane's step belongs to (DPP quad sums; used for 1-byte predicates)
+    uint32_t quad = my_cnt + dpp_or_zero<0xb1>(my_cnt);
+    quad += dpp_or_zero<0x4e>(quad);
+    if (c1 - c0 > kGroupSteps / kWaves && __popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
         // At most 16 non-empty steps in the whole range (a sparse answer): ONE round of loads fetches all their
         // match words, slot k of the LDS slice = the k-th of them (prefetched: slot = step - c0), and they are
         // expanded step by step.
@@ -1154,20 +1189,33 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
         // latency per window.  The slot of an empty step keeps whatever it held: nobody looks at it.
         {
             const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + w0) * 64) + lane;
-            for (uint32_t rest = bits; rest; rest &= rest - 1) {    // uniform
-                const uint32_t k = (uint32_t)__builtin_ctz(rest);
-                if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
-            }
+            if (!(have && w0 == c0))                                // (prefetched: the words of this window are on their way already)
+                for (uint32_t rest = bits; rest; rest &= rest - 1) {    // uniform
+                    const uint32_t k = (uint32_t)__builtin_ctz(rest);
+                    if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
+                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not count LDS-DMA as a write to LDS)
+            if (c0 == 0 && w0 == 0) PQPS_STAMP_GROUP(a, g, 5);
         }
-        for (uint32_t rest = bits; rest; rest &= rest - 1) {        // uniform
-            const uint32_t k = (uint32_t)__builtin_ctz(rest);
-            const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(w0 + k));
-            expand_step<GATHER>(a, ex.begin, g * kGroupSteps + w0 + k, sh.mask[park][k], rpl_log2, cwi & kCountMask, lane, ring, r);
+        for (uint32_t bb = 0; bb < 4; bb++) {                       // blocks of 4 steps
+            const uint32_t nb = (bits >> (4 * bb)) & 0xFu;
+            if (!nb) continue;
+            const uint32_t sidx0 = w0 + 4 * bb;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
+            if (rpl_log2 == 4 && total <= kBlockIds) {              // uniform
+                expand_block16<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
+                continue;
+            }
+            for (uint32_t i = 0; i < 4; i++) {
+                if (!((nb >> i) & 1u)) continue;
+                const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i));
+                expand_step<GATHER>(a, ex.begin, g * kGroupSteps + sidx0 + i, sh.mask[park][4 * bb + i], rpl_log2, cwi & kCountMask, lane, ring, r);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // reads done before the slice is filled again
     }
     if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+    if (c0 == 0) PQPS_STAMP_GROUP(a, g, 6);
 }
 
 // The leader wave of group g settles what the group needs: waits (bounded) for its count words and for the sums
