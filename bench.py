@@ -515,7 +515,7 @@ def _leaves(chain):
             yield x
 
 
-def time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps=20):
+def time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps=20, stream=None):
     """One query shape, one launch at a time on one stream, HIP events on the dispatch; consecutive launches
     alternate between the table copies.  -> dict (whole-query numbers; COUNT(*): scan + 1-workgroup reduction)."""
     bound = [t.bind(chain) for t in tables]
@@ -537,9 +537,29 @@ def time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, to
     ctx.set_timing(False)
     matches = int(cnt[0].item())
     byts = count * bpr + (4 * matches if mode == "ids" else 8)
-    return {"rows_per_s": count / (pipe / k * 1e-3), "matches": matches, "bytes_per_row": bpr,
-            "GBps": byts / (pipe / k * 1e-3) / 1e9, "frac_of_8TBps": byts / (pipe / k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "scan_kernel_ms": ms / k, "avg_query_ms": pipe / k}
+    out = {"rows_per_s": count / (pipe / k * 1e-3), "matches": matches, "bytes_per_row": bpr,
+           "GBps": byts / (pipe / k * 1e-3) / 1e9, "frac_of_8TBps": byts / (pipe / k * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "scan_kernel_ms": ms / k, "avg_query_ms": pipe / k}
+    if mode == "ids" and stream is not None:
+        # the same queries as `value` is produced: a stream, two in flight (wall clock over the batch, results left on the device)
+        qs, ring = stream
+        n_q = max(2 * reps, 20)
+        for i in range(len(ring)):
+            pred, cols, nc, _ = bound[i % len(bound)]
+            pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), ring[i][0].data_ptr(), ring[i][0].numel(), ring[i][1].data_ptr(), sptr))
+        pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_q):
+            pred, cols, nc, _ = bound[i % len(bound)]
+            b = ring[i % len(ring)]
+            pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), b[0].data_ptr(), b[0].numel(), b[1].data_ptr(), sptr))
+        pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
+        dt = (time.perf_counter() - t0) / n_q
+        assert int(ring[(n_q - 1) % len(ring)][1][0].item()) == matches
+        out["stream_ms_per_query"] = dt * 1e3
+        out["stream_frac_of_8TBps"] = byts / dt / 1e9 / HBM_PEAK_GBPS
+    return out
 
 
 def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log, alloc, seed):
@@ -551,14 +571,22 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
     ids = torch.empty(max(count, 1), dtype=torch.int32, device=device)
     cnt = torch.zeros(2, dtype=torch.int64, device=device)
     reps = 20
+    # a query stream of its own for the "as a stream" figures: three result buffers (pqps_qstream keeps two queries in flight)
+    qs = C.c_void_p()
+    pq.check(L.pqps_qstream_create(ctx.h, 3, C.byref(qs)), "pqps_qstream_create")
+    ring = [(ids, cnt)] + [(torch.empty(max(count, 1), dtype=torch.int32, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+                           for _ in range(2)]
     for name in names:
         chain, sql = QUERIES[name]
         for mode in ("ids", "count"):
-            r = time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps)
+            r = time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, torch, reps, stream=(qs, ring))
             r["query"] = sql
             out[f"{name}_{mode}"] = r
             log(f"{name:>5} {mode:>5}: {r['avg_query_ms'] * 1e3:7.1f} us  {r['rows_per_s'] / 1e9:7.1f} G rows/s  {r['GBps']:5.0f} GB/s "
-                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s), {r['matches']:,} matches")
+                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s), {r['matches']:,} matches"
+                + (f"; as a stream {r['stream_ms_per_query'] * 1e3:.1f} us per query ({100 * r['stream_frac_of_8TBps']:.1f} %)" if "stream_ms_per_query" in r else ""))
+    del ring[1:]
+    torch.cuda.empty_cache()
     # ---- configs[2]: index range-probe SELECT (sorted-permutation index = B+-tree leaf order) --------
     # bytes per SURVEY 8(d): slice_len * (4 [perm] + sum of gathered predicate column widths) + 4 * matches
     have = set(table.ptr)
@@ -658,16 +686,20 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
     n1b = 1_000_000_000
     big = pq.SyntheticTable(ctx, n1b, seed=seed, row0=0, columns=["sudo_used", "user_name", "risk_level"], alloc=alloc, stream=sptr)
     ids = torch.empty(n1b // 8, dtype=torch.int32, device=device)
+    ring = [(ids, cnt)] + [(torch.empty(n1b // 8, dtype=torch.int32, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+                           for _ in range(2)]
     ns = {"rows": n1b}
     for name in ("S1", "Q_A", "Q_B"):
         chain, sql = QUERIES[name]
         for mode in ("ids", "count"):
-            r = time_query(pq, L, ctx, [big], chain, mode, n1b, 0, ids, cnt, sptr, torch, reps=10)
+            r = time_query(pq, L, ctx, [big], chain, mode, n1b, 0, ids, cnt, sptr, torch, reps=10, stream=(qs, ring))
             r["query"] = sql
             ns[f"{name}_{mode}"] = r
             log(f"1 G rows {name:>4} {mode:>5}: {r['avg_query_ms'] * 1e3:7.1f} us  {r['rows_per_s'] / 1e12:5.2f} T rows/s  "
-                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s whole query)")
+                f"({100 * r['frac_of_8TBps']:.1f} % of 8 TB/s whole query)"
+                + (f"; as a stream {r['stream_ms_per_query'] * 1e3:.1f} us ({100 * r['stream_frac_of_8TBps']:.1f} %)" if "stream_ms_per_query" in r else ""))
     out["north_star_1b"] = ns
+    pq.check(L.pqps_qstream_destroy(qs), "pqps_qstream_destroy")
     return out
 
 
