@@ -44,6 +44,8 @@ QUERIES = {
     "S7": [("sudo_used", "=", "TRUE"), "OR", [("risk_level", "=", "5"), "AND", ("shell_type", "=", "bash")]],
     "S8": [("user_id", "=", "1001"), "OR", [("user_name", "=", "student1002"), "AND", ("shell_type", "=", "zsh")]],
     "cid_range": [("command_id", ">=", "1000"), "AND", ("command_id", "<", "70000")],
+    "u8": [("sudo_used", "=", "TRUE")],                        # one 1-byte column, ~7 %: four steps per wave scan in the expander
+    "u8_dict": [("shell_type", "=", "zsh")],
     "all": [],
     "none": [("risk_level", ">", "9")],
     "neq": [("risk_level", "!=", "1")],

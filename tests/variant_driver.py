@@ -26,6 +26,8 @@ QUERIES = {
     "Q_C": [("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1500"), "OR", ("risk_level", "=", "5")],
     "S7": [("sudo_used", "=", "TRUE"), "OR", [("risk_level", "=", "5"), "AND", ("shell_type", "=", "bash")]],
     "dense": [("sudo_used", "=", "FALSE")],
+    "u8": [("sudo_used", "=", "TRUE")],                        # one 1-byte column, ~7 %: four steps per wave scan in the expander
+    "u8_dict": [("shell_type", "=", "zsh")],
     "all": [],
     "none": [("risk_level", ">", "9")],
     "seven_leaves": [("risk_level", "=", "1"), "OR", ("risk_level", "=", "2"), "AND", ("exit_code", "=", "0"), "OR",
