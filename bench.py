@@ -257,7 +257,7 @@ def main():
     # N = 1: a stream of queries -- the expanders behind the last scan tile of query k run on a second
     # stream under the scan tiles of query k+1
     qs = None
-    if not exchange and not args.no_pipeline and not count_mode:
+    if not exchange and not args.no_pipeline:
         qs = C.c_void_p()
         pq.check(L.pqps_qstream_create(ctx.h, RING, C.byref(qs)), "pqps_qstream_create")
     xch, mergers = None, None
@@ -290,8 +290,11 @@ def main():
         if qs is not None:
             # slot r is free again once the query that last used it (k - RING) has finished: a host-side wait
             # inside the call, normally already satisfied, so the scan stream carries no cross-stream barrier
-            pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap, m.count_ptr, sptr),
-                     "pqps_qstream_scan")
+            if count_mode:
+                pq.check(L.pqps_qstream_count(qs, cols, nc, count, C.byref(pred), count_out[2 * r:].data_ptr(), sptr), "pqps_qstream_count")
+            else:
+                pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), m.ids_ptr, m.cap, m.count_ptr, sptr),
+                         "pqps_qstream_scan")
             return
         merge_done[r].synchronize()
         if count_mode:

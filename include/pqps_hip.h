@@ -241,6 +241,10 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out);
 int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
                       const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
                       void *scan_stream);
+/* COUNT(*) through the same two lanes: pqps_filter_count with two queries in flight; the caller keeps a ring of
+ * `depth` out_count words. */
+int pqps_qstream_count(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                       const pqps_predicate *pred, uint64_t *out_count, void *scan_stream);
 int pqps_qstream_sync(pqps_qstream *q);
 /* Host time (ns) pqps_qstream_scan has spent waiting for an output pair to come free -- as opposed to time inside
  * runtime calls; `reset` != 0 clears the counter. */

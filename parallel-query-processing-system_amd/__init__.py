@@ -259,6 +259,7 @@ def lib():
     L.pqps_merge_slots.argtypes = [vp, vp, u32, u64, vp, u64, vp, vp]
     L.pqps_qstream_create.argtypes = [vp, u32, C.POINTER(vp)]
     L.pqps_qstream_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
+    L.pqps_qstream_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
     L.pqps_qstream_sync.argtypes = [vp]
     L.pqps_qstream_wait_ns.argtypes = [vp, C.c_int]
     L.pqps_qstream_wait_ns.restype = u64

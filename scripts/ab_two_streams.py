@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--prio", default="", help="priorities of the two streams, e.g. -1,0 (empty: default streams)")
     ap.add_argument("--copies", type=int, default=2)
+    ap.add_argument("--count", action="store_true", help="COUNT(*) instead of ID lists (the one- / N-context legs)")
     ap.add_argument("--ring", type=int, default=6, help="result slots of the exchange")
     ap.add_argument("--exchange", action="store_true", help="also time pqps_exchange_select with a world of one")
     ap.add_argument("--streams", type=int, default=2, help="contexts (streams) the queries go round")
@@ -52,7 +53,10 @@ def main():
         pred, cols, nc, _ = bound[k % len(bound)]
         c = ctxs[which]
         ids, cnt = outs[which]
-        pq.check(L.pqps_filter_scan(c.h, cols, nc, n, 0, C.byref(pred), ids, n // 2, cnt, None))
+        if args.count:
+            pq.check(L.pqps_filter_count(c.h, cols, nc, n, C.byref(pred), cnt, None))
+        else:
+            pq.check(L.pqps_filter_scan(c.h, cols, nc, n, 0, C.byref(pred), ids, n // 2, cnt, None))
 
     # the same through the shim's query stream (pqps_qstream_scan: two lanes, completion events on the dispatch packets)
     qs = C.c_void_p()

@@ -277,10 +277,10 @@ def test_native_exchange_world_of_one(ctx):
 
 
 def test_query_stream_keeps_queries_apart(ctx):
-    """pqps_qstream_*: K1 of query k+1 runs while K2 / K3 of query k are still compacting on the
-    second stream.  40 queries of 6 different shapes (sparse, dense, > 6 leaves -> generic kernel,
-    empty) go through a depth-3 stream back to back, each with its own output buffer; every answer
-    must equal the oracle's, and a sync in the middle must not disturb the sequence."""
+    """pqps_qstream_*: two queries in flight, each whole on one of the stream's two lanes.  40 ID queries of 6
+    different shapes (sparse, dense, > 6 leaves -> generic kernel, empty) go through a depth-3 stream back to
+    back, each with its own output buffer, COUNT(*) queries (pqps_qstream_count) in between; every answer must
+    equal the oracle's, and a sync in the middle must not disturb the sequence."""
     L = pq.lib()
     n = 700_001
     host = q.HostSynth(n, seed=17)
@@ -292,6 +292,7 @@ def test_query_stream_keeps_queries_apart(ctx):
     pq.check(L.pqps_qstream_create(ctx.h, 3, C.byref(qs)), "pqps_qstream_create")
     assert L.pqps_qstream_create(ctx.h, 1, C.byref(C.c_void_p())) == -1           # depth >= 2
     outs = [DeviceOut(ctx, n) for _ in range(8)]
+    counts = ctx.malloc(8 * 8)
     try:
         order = [names[(3 * i + i // 5) % len(names)] for i in range(40)]
         for base in range(0, 40, 8):                                  # 8 queries in flight per batch of buffers
@@ -299,11 +300,17 @@ def test_query_stream_keeps_queries_apart(ctx):
                 pred, cols, nc, _ = bound[name]
                 pq.check(L.pqps_qstream_scan(qs, cols, nc, n, 0, C.byref(pred), outs[j].ids, outs[j].cap, outs[j].count, None),
                          "pqps_qstream_scan")
+                if j % 3 != 2:                                        # ... and its COUNT(*) right behind, on the other lane
+                    pq.check(L.pqps_qstream_count(qs, cols, nc, n, C.byref(pred), counts + 8 * j, None), "pqps_qstream_count")
             pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
             ctx.sync()
+            got_counts = (C.c_uint64 * 8)()
+            ctx.download(got_counts, counts, 64)
             for j, name in enumerate(order[base:base + 8]):
                 k = outs[j].read_count()
                 assert k == len(want[name]) and np.array_equal(outs[j].read_ids(k), want[name]), (base + j, name)
+                if j % 3 != 2:
+                    assert got_counts[j] == len(want[name]), (base + j, name)
         # capacity overflow is still reported through the count, nothing is written past the buffer
         pred, cols, nc, _ = bound["Q_A"]
         small = DeviceOut(ctx, 100)
@@ -313,6 +320,7 @@ def test_query_stream_keeps_queries_apart(ctx):
         small.free()
     finally:
         pq.check(L.pqps_qstream_destroy(qs))
+        ctx.free(counts)
         for o in outs:
             o.free()
         dev.free()
