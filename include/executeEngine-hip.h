@@ -19,7 +19,9 @@
  * There is no CPU fallback: without a gfx950 device / the HIP runtime
  * initializeEngineHIP prints the reason and exits, like the reference's engines on a failed start-up
  * allocation.  A query that fails later (a WHERE that cannot be compiled, a device error) prints the reason
- * and reports failure -- success = false / -1 -- and the engine stays usable.
+ * and reports failure -- success = false / -1 -- and the engine stays usable.  (A device step that fails in
+ * the middle of an INSERT / DELETE -- after the CSV and the host rows have changed -- is still fatal: the device
+ * table could not be trusted afterwards.)
  */
 #ifndef EXECUTE_ENGINE_HIP_H
 #define EXECUTE_ENGINE_HIP_H
