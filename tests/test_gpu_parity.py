@@ -46,6 +46,8 @@ QUERIES = {
     "cid_range": [("command_id", ">=", "1000"), "AND", ("command_id", "<", "70000")],
     "u8": [("sudo_used", "=", "TRUE")],                        # one 1-byte column, ~7 %: four steps per wave scan in the expander
     "u8_dict": [("shell_type", "=", "zsh")],
+    "mid": [("risk_level", ">", "1")],                          # ~43 %: steps of ~440 matches (staged 64-row path)
+    "mid_u8": [("shell_type", "!=", "bash")],
     "all": [],
     "none": [("risk_level", ">", "9")],
     "neq": [("risk_level", "!=", "1")],

@@ -28,6 +28,8 @@ QUERIES = {
     "dense": [("sudo_used", "=", "FALSE")],
     "u8": [("sudo_used", "=", "TRUE")],                        # one 1-byte column, ~7 %: four steps per wave scan in the expander
     "u8_dict": [("shell_type", "=", "zsh")],
+    "mid": [("risk_level", ">", "1")],                          # ~43 %: steps of ~440 matches (staged 64-row path)
+    "mid_u8": [("shell_type", "!=", "bash")],
     "all": [],
     "none": [("risk_level", ">", "9")],
     "seven_leaves": [("risk_level", "=", "1"), "OR", ("risk_level", "=", "2"), "AND", ("exit_code", "=", "0"), "OR",
