@@ -43,25 +43,42 @@ struct hipIndex {
     void *keys_dev;          /* n keys, column width                       */
 };
 
-/* Locks of one engine (engine/hip/buildEngine-hip.c).  The OpenMP driver of the reference calls
- * the engine from several threads at once (QPEOMP.c:234-291); SELECT / COUNT hold `rows` shared and
- * `device` for their device phase (the context's scratch serves one query at a time), INSERT /
- * DELETE / index creation hold `rows` exclusively. */
+/* Locks of one engine (engine/hip/buildEngine-hip.c).  The OpenMP driver of the reference calls the engine
+ * from several threads at once (QPEOMP.c:234-291).  SELECT / COUNT are READERS: each takes one of the table's
+ * query LANES (result buffers of its own on every shard + a slot of the shards' query streams, pqps_qstream),
+ * so several of them are on the device at once and none waits for another's result download; INSERT / DELETE /
+ * index creation are WRITERS and run alone.  A reader may be finished by another thread than the one that began
+ * it (asynchronous tickets), hence a counting gate and not a pthread rwlock. */
 struct hipLocks;
+
+/* Result buffers of one query in flight on one shard. */
+struct hipLane {
+    uint32_t *ids_dev;                           /* row numbers of the result, capacity_ids u32                 */
+    uint64_t capacity_ids;
+    uint64_t *count_dev;                         /* 8 x u64: count, spare, range[2], flag-pass count, spare ... */
+    pqps_ctx *copy;                              /* context (stream) for this lane's downloads / gathers; NULL: the table's */
+    uint32_t *merged_dev;                        /* shard 0 only, several shards: the gathered list of all shards */
+    uint64_t merged_cap;
+};
+
+#define HIP_MAX_LANES 8
 
 /* Device-resident table; hangs off engineS.record_block (same address for the engine's life). */
 struct hipTable {
     pqps_ctx *ctx;
     uint64_t n_rows;
     uint64_t capacity_rows;                      /* allocation, multiple of PQPS_TILE_ROWS */
-    pqps_column col[HIPCOL_COUNT];               /* device buffers                         */
+    pqps_column col[HIPCOL_COUNT];               /* device buffers; a dictionary column with ONE value may have none
+                                                    (data NULL, width 0): every row carries code 0                  */
     struct hipDictionary dict[HIPCOL_COUNT];     /* string columns only                    */
     struct hipIndex *index;                      /* engine->num_indexes entries            */
-    uint32_t *ids_dev;                           /* result scratch, capacity_ids u32       */
-    uint64_t capacity_ids;
-    uint64_t *count_dev;                         /* 4 x u64: count, range[2], spare        */
-    record *row_block;                           /* contiguous host rows (all_records[i] point in) */
+    struct hipLane own;                          /* the table's own result buffers: writers, ad-hoc tables          */
+    pqps_qstream *qs;                            /* engine tables: this shard's query stream, n_lanes slots         */
+    int n_lanes;
+    struct hipLane lane[HIP_MAX_LANES];
+    record *row_block;                           /* contiguous host rows (all_records[i] point in); NULL: device only */
     size_t row_capacity;                         /* rows row_block / all_records have room for      */
+    int device_only;                             /* the engine has no host rows (initializeEngineColumnsHIP / SyntheticHIP) */
     struct hipLocks *locks;                      /* engine tables only; NULL for ad-hoc tables      */
     /* Several devices in one process (PQPS_DEVICES=0,1,...): the engine's rows are split into contiguous
      * shards by the reference's block partition (executeEngine-mpi.c:703-715), one device table each.
@@ -78,10 +95,15 @@ static inline struct hipTable *hipTableShard(struct hipTable *t, int s) { return
 
 /* No-ops on a table without locks. */
 void hipTableLockShared(struct hipTable *t);
+void hipTableUnlockShared(struct hipTable *t);
 void hipTableLockExclusive(struct hipTable *t);
-void hipTableUnlock(struct hipTable *t);
-void hipTableLockDevice(struct hipTable *t);
-void hipTableUnlockDevice(struct hipTable *t);
+void hipTableUnlockExclusive(struct hipTable *t);
+/* A free query lane of the table (blocks while all are taken); -1 on a table without lanes. */
+int  hipTableAcquireLane(struct hipTable *t);
+void hipTableReleaseLane(struct hipTable *t, int lane);
+/* Issuing calls on the shards' query streams are serialised (they take microseconds). */
+void hipTableLockIssue(struct hipTable *t);
+void hipTableUnlockIssue(struct hipTable *t);
 
 /* CSV -> contiguous block of records + pointer array (reference signature of
  * getAllRecordsFromFileOMP, buildEngine-omp.h:31). */
@@ -105,12 +127,22 @@ bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *futu
 /* Re-creates columns, dictionaries and indexes from engine->all_records
  * (after INSERT / DELETE changed the host rows). */
 void rebuildDeviceTableHIP(struct engineS *engine);
-/* INSERT: appends engine->all_records[num_records-1] to the device table (its last shard) in place. */
-void appendRowDeviceTableHIP(struct engineS *engine);
+/* INSERT: appends `r` (row number engine->num_records - 1) to the device table (its last shard) in place; false
+ * when that needs a rebuild which a device-only engine cannot do (a dictionary outgrowing its code width). */
+bool appendRowDeviceTableHIP(struct engineS *engine, const record *r);
 /* DELETE: `delete_flags_dev[s]` (1 = row goes, from pqps_filter_flags on shard s) compacts that shard's
  * device columns in place; `expected_rows` = survivors counted on the host over all shards (cross-check). */
 void compactDeviceTableHIP(struct engineS *engine, uint8_t *const *delete_flags_dev, size_t expected_rows);
 void destroyDeviceTableHIP(struct engineS *engine);
+
+/* Engines over device-resident columns (no host rows): see initializeEngineColumnsHIP / initializeEngineSyntheticHIP
+ * in executeEngine-hip.h.  `columns` describes all 12 columns of `record`. */
+struct hipColumnData;
+bool buildDeviceTableFromColumnsHIP(struct engineS *engine, unsigned long long num_rows, const struct hipColumnData *columns);
+bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed);
+/* Dictionary of a string column of the synthetic table (ascending strcmp order): the values behind the codes
+ * pqps_synth_generate produces; NULL for a numeric column. */
+const char *const *hipSyntheticDictionary(int column, int *count);
 
 /* Lower-level pieces (also used for ad-hoc tables over caller-supplied rows,
  * see linearSearchRecords / evaluateWhereClause in executeEngine-hip.c). */

@@ -98,6 +98,61 @@ char *hipColumnarCellText(const struct hipColumnarResult *result, int row, int c
 struct resultSetS *hipColumnarHead(const struct hipColumnarResult *result, int limit);
 void freeResultSetHead(struct resultSetS *head, int rows);
 
+/* ---- engines over device-resident columns: tables of 10^8 - 10^9 rows behind struct engineS --------------------
+ * initializeEngineHIP builds the device table from 1040-byte host rows (the reference's `record`); a 1 G-row table
+ * is 1.04 TB in that form and 26 GB as columns.  These two constructors build the SAME engine -- same query API,
+ * same results -- without host rows: engine->all_records is NULL, engine->datafile is "" (INSERT / DELETE change
+ * the device table only, no CSV is kept in step), and executeQuerySelectHIP produces its strings from values
+ * gathered on the device.
+ *
+ * initializeEngineColumnsHIP: the caller hands over the 12 columns of `record` (include/logType.h:11-24) as arrays:
+ *   numeric columns   command_id u64, exit_code / user_id / risk_level i32, sudo_used u8 (0 / 1)
+ *   string columns    order-preserving dictionary codes (u8 / u16 / u32 by `width`) + the dictionary, ascending in
+ *                     strcmp order, no duplicates; a column whose dictionary has ONE value needs no array
+ *   values            host memory, or (on_device != 0) device memory of the engine's device -- copied either way,
+ *                     the engine owns padded buffers with head-room for INSERT.
+ * initializeEngineSyntheticHIP: the seeded synthetic table of the commands_* schema (pqps_synth_generate,
+ * SURVEY.md App. B distributions), generated in place on the device(s); raw_command, timestamp and
+ * working_directory are single-valued columns.  With PQPS_DEVICES=0,1,... the rows are sharded like any engine's. */
+struct hipColumnData {
+    const void *values;                /* num_rows entries of `width` bytes; NULL for a single-valued string column */
+    unsigned int width;                /* bytes per entry: 8 / 4 / 1 as the column's type says; codes: 1, 2 or 4      */
+    int on_device;                     /* values is device memory (of the engine's first device)                      */
+    const char *const *dictionary;     /* string columns: `dictionary_count` C strings, ascending strcmp order         */
+    int dictionary_count;
+};
+struct engineS *initializeEngineColumnsHIP(unsigned long long num_rows, const struct hipColumnData columns[12],
+                                           int num_indexes, const char *indexed_attributes[], const int attribute_types[],
+                                           const char *tableName);
+struct engineS *initializeEngineSyntheticHIP(unsigned long long num_rows, unsigned long long seed,
+                                             int num_indexes, const char *indexed_attributes[], const int attribute_types[],
+                                             const char *tableName);
+
+/* ---- asynchronous queries: several in flight, results left on the device -----------------------------------------
+ * The engine's table has LANES (default 4, PQPS_ENGINE_LANES): result buffers + a slot of the table's query stream
+ * (pqps_qstream: two launches in flight on two HIP streams, one for tables of 268 M rows and more).  Every SELECT /
+ * COUNT takes a lane for its device phase -- concurrent callers of the synchronous functions (the reference's OpenMP
+ * driver, QPEOMP.c:234-291) therefore overlap on the device -- and a caller can keep several queries in flight itself:
+ *   t = executeQuerySelectAsyncHIP(engine, where)     enqueues the query (blocks only while every lane is taken)
+ *   n = awaitQueryHIP(t, &result)                     waits for it: number of matching rows, -1 on error
+ *   ...                                               result.ids_dev: the row numbers in QPESeq order, ON THE DEVICE
+ *   releaseQueryHIP(t)                                the lane is free again, result.ids_dev is no longer valid
+ * With several shards the shards' lists are gathered on shard 0's device by peer copies (the one-process form of
+ * MPI_Allgather of the sizes + MPI_Allgatherv of the payload, engine/mpi/executeEngine-mpi.c:753-765; index mode:
+ * merged by key on the device).  executeQueryCountAsyncHIP: COUNT(*), no list.  A ticket must be released. */
+struct hipQueryTicket;
+struct hipDeviceResult {
+    long long count;                   /* matching rows (COUNT: the only field that means anything)     */
+    const unsigned int *ids_dev;       /* `count` row numbers, device memory of device `device`         */
+    int device;
+    int n_shards;
+    unsigned long long shard_count[16];/* matches found by each shard                                    */
+};
+struct hipQueryTicket *executeQuerySelectAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause);
+struct hipQueryTicket *executeQueryCountAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause);
+long long awaitQueryHIP(struct hipQueryTicket *ticket, struct hipDeviceResult *result /* may be NULL */);
+void releaseQueryHIP(struct hipQueryTicket *ticket);
+
 /* Number of device shards the engine's table is split into (1 unless PQPS_DEVICES names several devices);
  * `rows` (may be NULL, room for that many entries) receives the rows each shard holds. */
 int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity);

@@ -98,6 +98,9 @@ typedef struct pqps_predicate {
 typedef struct pqps_ctx pqps_ctx;
 
 const char *pqps_last_error(void);
+/* The kernel instantiation the calling thread's last filter call chose, as rocprofv3 would name it
+ * (e.g. "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT=true, VC=false>"): what bench.py reports. */
+const char *pqps_last_kernel(void);
 
 /* Context = device ordinal + stream + filter scratch (match bits, step / group / supergroup
  * counts; grown on demand).  One query at a time per context; use one context per host thread. */
@@ -108,6 +111,7 @@ void pqps_ctx_destroy(pqps_ctx *ctx);
 int  pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 int  pqps_device_count(void);
+int  pqps_ctx_device(pqps_ctx *ctx);
 /* Per-launch HIP-event timing of the filter (up to 4096 launches per reset).
  * The scan kernel carries its own begin / end events on the dispatch packet, i.e. the timestamps rocprofv3
  * --kernel-trace reports.  pqps_ctx_kernel_time waits for the recorded launches and returns: *eval_ms = sum of
@@ -127,6 +131,11 @@ int  pqps_free(pqps_ctx *ctx, void *dptr);
 int  pqps_memset(pqps_ctx *ctx, void *dptr, int value, size_t bytes, void *stream);
 int  pqps_upload(pqps_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int  pqps_download(pqps_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+/* Device-to-device copy between the devices of two contexts (or inside one), asynchronous on `stream` of the
+ * DESTINATION context (NULL: its own stream): what the one-process engine gathers its shards' results with
+ * (peer DMA over xGMI -- the one-process counterpart of the send / recv pairs of pqps_exchange, which in turn
+ * stand for MPI_Allgatherv, engine/mpi/executeEngine-mpi.c:765). */
+int  pqps_copy_peer(pqps_ctx *dst_ctx, void *dst, pqps_ctx *src_ctx, const void *src, size_t bytes, void *stream);
 
 /* codes[i] += 1 for every i < n_rows with codes[i] >= threshold (`width` 1, 2 or 4 bytes).
  * Keeps the dictionary codes of a string column order-preserving when INSERT adds a value
@@ -250,6 +259,30 @@ int pqps_qstream_sync(pqps_qstream *q);
  * runtime calls; `reset` != 0 clears the counter. */
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset);
 int pqps_qstream_destroy(pqps_qstream *q);
+
+/* The same with the SLOT named by the caller (0 .. depth-1) instead of call number % depth: what an engine with
+ * several host threads needs -- a thread takes a free slot, issues, waits for THAT slot and reads its result, while
+ * other threads do the same on other slots (the reference's OpenMP driver, QPEOMP.c:234-291).  Issuing calls on one
+ * query stream must not overlap (the caller serialises them, e.g. under a mutex: they take microseconds);
+ * pqps_qstream_wait may run concurrently with anything.  A slot is reused only after its query has been waited for.
+ * Tables of 268 M rows and more use ONE lane (their launches keep expanders among the scan tiles, the tail is a few
+ * percent of the launch, and two launches side by side lose more than the overlap gains). */
+int pqps_qstream_scan_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                           const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *scan_stream);
+int pqps_qstream_count_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                            const pqps_predicate *pred, uint64_t *out_count, void *scan_stream);
+/* Host wait for the query of ONE slot; reports (once) a launch whose bounded waits ran out. */
+int pqps_qstream_wait(pqps_qstream *q, uint32_t slot);
+/* A query that is more than one filter call (index probes + gather filters, flag passes in front of the last pass):
+ * pqps_qstream_lane hands out the lane context + HIP stream the slot's query is to run on (call the pqps_filter_* /
+ * pqps_index_probe functions with them), pqps_qstream_mark records its end on that stream. */
+int pqps_qstream_lane(pqps_qstream *q, uint32_t slot, uint64_t n_rows, void *scan_stream, pqps_ctx **lane_ctx, void **lane_stream);
+int pqps_qstream_mark(pqps_qstream *q, uint32_t slot);
+/* Per-launch timing of the queries AS THEY RUN IN THE STREAM (two in flight): the lanes' own recorders, events on
+ * the dispatch packets (recording does not change how the launches overlap).  pqps_qstream_kernel_time = the sums of
+ * pqps_ctx_kernel_time over the lanes. */
+int pqps_qstream_set_timing(pqps_qstream *q, int enable);
+int pqps_qstream_kernel_time(pqps_qstream *q, double *eval_ms, double *total_ms, int *launches);
 
 /* ---- multi-GPU SELECT: shard scan + all-gatherv of the matching row IDs over RCCL, one host call per query ----
  * Replaces the exchange step of engine/mpi/executeEngine-mpi.c:717-768 and keeps its shape: local scan of

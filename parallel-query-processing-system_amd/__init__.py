@@ -94,6 +94,18 @@ class ColumnarResult(C.Structure):
                 ("queryTime", C.c_double), ("success", C.c_bool)]
 
 
+class ColumnData(C.Structure):
+    """struct hipColumnData (include/executeEngine-hip.h)."""
+    _fields_ = [("values", C.c_void_p), ("width", C.c_uint), ("on_device", C.c_int),
+                ("dictionary", C.POINTER(C.c_char_p)), ("dictionary_count", C.c_int)]
+
+
+class DeviceResult(C.Structure):
+    """struct hipDeviceResult (include/executeEngine-hip.h)."""
+    _fields_ = [("count", C.c_longlong), ("ids_dev", C.c_void_p), ("device", C.c_int), ("n_shards", C.c_int),
+                ("shard_count", C.c_ulonglong * 16)]
+
+
 class EngineS(C.Structure):
     _fields_ = [
         ("tableName", C.c_char_p),
@@ -224,6 +236,9 @@ def lib():
     W = C.POINTER(WhereClause)
     vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
     L.pqps_last_error.restype = C.c_char_p
+    L.pqps_last_kernel.restype = C.c_char_p
+    L.pqps_ctx_device.argtypes = [vp]
+    L.pqps_copy_peer.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.pqps_device_count.restype = C.c_int
     L.pqps_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.pqps_ctx_destroy.argtypes = [vp]
@@ -261,6 +276,13 @@ def lib():
     L.pqps_qstream_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
     L.pqps_qstream_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
     L.pqps_qstream_sync.argtypes = [vp]
+    L.pqps_qstream_scan_slot.argtypes = [vp, u32, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
+    L.pqps_qstream_count_slot.argtypes = [vp, u32, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
+    L.pqps_qstream_wait.argtypes = [vp, u32]
+    L.pqps_qstream_lane.argtypes = [vp, u32, u64, vp, C.POINTER(vp), C.POINTER(vp)]
+    L.pqps_qstream_mark.argtypes = [vp, u32]
+    L.pqps_qstream_set_timing.argtypes = [vp, C.c_int]
+    L.pqps_qstream_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.pqps_qstream_wait_ns.argtypes = [vp, C.c_int]
     L.pqps_qstream_wait_ns.restype = u64
     L.pqps_exchange_wait_ns.argtypes = [vp, C.c_int]
@@ -288,6 +310,20 @@ def lib():
     E = C.POINTER(EngineS)
     L.initializeEngineHIP.restype = E
     L.initializeEngineHIP.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_char_p, C.c_char_p]
+    L.initializeEngineSyntheticHIP.restype = E
+    L.initializeEngineSyntheticHIP.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_char_p]
+    L.initializeEngineColumnsHIP.restype = E
+    L.initializeEngineColumnsHIP.argtypes = [C.c_ulonglong, C.POINTER(ColumnData), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_char_p]
+    L.hipSyntheticDictionary.restype = C.POINTER(C.c_char_p)
+    L.hipSyntheticDictionary.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    for name in ("executeQuerySelectAsyncHIP", "executeQueryCountAsyncHIP"):
+        f = getattr(L, name)
+        f.restype = vp
+        f.argtypes = [E, W]
+    L.awaitQueryHIP.restype = C.c_longlong
+    L.awaitQueryHIP.argtypes = [vp, C.POINTER(DeviceResult)]
+    L.releaseQueryHIP.argtypes = [vp]
+    L.releaseQueryHIP.restype = None
     L.destroyEngineHIP.argtypes = [E]
     L.destroyEngineHIP.restype = None
     L.executeQuerySelectHIP.restype = C.POINTER(ResultSet)
@@ -452,6 +488,8 @@ SYNTH_HOSTS = sorted([b"labpc-01", b"labpc-02", b"labpc-03", b"labpc-04", b"labp
                       b"cs-lab-01", b"cs-lab-02", b"personal-laptop", b"remote-ssh-01"])
 SYNTH_USERS_DICT = [b"student%d" % (1000 + i) for i in range(SYNTH_USERS)]
 SYNTH_BASES = sorted(b"cmd%03d" % i for i in range(111))
+# the single-valued string columns of the synthetic ENGINE table (initializeEngineSyntheticHIP)
+SYNTH_CONSTANTS = {"raw_command": b"cmd", "timestamp": b"2025-01-01T00:00:00.000Z", "working_directory": b"/home/u"}
 # (record column, SynthCols field, bytes per row)
 SYNTH_LAYOUT = [("command_id", "command_id", 8), ("exit_code", "exit_code", 4), ("user_id", "user_id", 4),
                 ("risk_level", "risk_level", 4), ("sudo_used", "sudo_used", 1), ("shell_type", "shell_code", 1),
@@ -533,6 +571,68 @@ class HipEngine:
         types = (C.c_int * max(1, len(indexes)))(*[t for _, t in indexes])
         self.e = L.initializeEngineHIP(len(indexes), names, types, str(csv_path).encode(), b"commands")
         self.n = self.e.contents.num_records
+
+    @classmethod
+    def _index_args(cls, indexes):
+        names = (C.c_char_p * max(1, len(indexes)))(*[a.encode() for a, _ in indexes])
+        types = (C.c_int * max(1, len(indexes)))(*[t for _, t in indexes])
+        return names, types
+
+    @classmethod
+    def synthetic(cls, n_rows, seed=0x5EED, indexes=()):
+        """initializeEngineSyntheticHIP: the seeded synthetic table behind the engine API, no host rows."""
+        self = cls.__new__(cls)
+        names, types = cls._index_args(indexes)
+        self.e = lib().initializeEngineSyntheticHIP(n_rows, seed, len(indexes), names, types, b"commands")
+        if not self.e:
+            raise PqpsError("initializeEngineSyntheticHIP failed")
+        self.n = self.e.contents.num_records
+        return self
+
+    @classmethod
+    def from_columns(cls, n_rows, columns, indexes=()):
+        """initializeEngineColumnsHIP.  columns: {name: numpy array} for numeric columns,
+        {name: (codes array or None, [bytes, ...] dictionary)} for string columns (all 12 of them)."""
+        import numpy as np
+        self = cls.__new__(cls)
+        arr = (ColumnData * MAX_COLUMNS)()
+        keep = []
+        for i, name in enumerate(COLUMNS):
+            v = columns[name]
+            if COLUMN_KIND[i] == KIND_DICT:
+                codes, values = v
+                d = (C.c_char_p * max(1, len(values)))(*values)
+                keep.append(d)
+                arr[i].dictionary, arr[i].dictionary_count = d, len(values)
+                if codes is not None:
+                    codes = np.ascontiguousarray(codes)
+                    keep.append(codes)
+                    arr[i].values, arr[i].width = codes.ctypes.data, codes.dtype.itemsize
+            else:
+                a = np.ascontiguousarray(v)
+                keep.append(a)
+                arr[i].values, arr[i].width = a.ctypes.data, a.dtype.itemsize
+        names, types = cls._index_args(indexes)
+        self.e = lib().initializeEngineColumnsHIP(n_rows, arr, len(indexes), names, types, b"commands")
+        if not self.e:
+            raise PqpsError("initializeEngineColumnsHIP failed")
+        self.n = self.e.contents.num_records
+        return self
+
+    def select_async(self, chain, count_only=False):
+        """-> ticket (opaque).  The WHERE list only has to live until this call returns."""
+        wl = WhereList(chain)
+        f = lib().executeQueryCountAsyncHIP if count_only else lib().executeQuerySelectAsyncHIP
+        return f(self.e, wl.ptr)
+
+    def await_ticket(self, ticket):
+        """-> (count, DeviceResult)."""
+        res = DeviceResult()
+        k = lib().awaitQueryHIP(ticket, C.byref(res))
+        return k, res
+
+    def release_ticket(self, ticket):
+        lib().releaseQueryHIP(ticket)
 
     def select_ids(self, chain):
         wl = WhereList(chain)

@@ -543,7 +543,11 @@ constexpr uint32_t kDirectIds = 192;        // a step with at most this many mat
 constexpr uint32_t kBlockIds = 448;         // 1-byte columns: FOUR steps with at most this many matches between them are ranked as one block
 constexpr uint32_t kStageRing = 512;        // >= max(kDirectIds, kBlockIds) + 63
 constexpr uint32_t kSoloIds = 256;          // a trailing group with at most this many matches is expanded by its leader wave alone
-constexpr uint32_t kRecoverSpins = 1u << 26; // the recovery pass gives up (sticky status word) after this many polls
+constexpr uint32_t kRecoverSpins = 1u << 26; // "the long wait" (recovery pass, gather leaders): bounded by WALL CLOCK, see kRecoverTicks
+// A wait that the grid's layout guarantees to end (what is waited for are scan tiles, which wait for nothing) still
+// gets a deadline: 250 ms of the 100 MHz wall clock -- far beyond any launch, far below what a watchdog calls a hang.
+// When it runs out the sticky status word is set; the host reports it once and resets the hand-off words.
+constexpr uint64_t kRecoverTicks = 25000000ull;
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
 constexpr int kRplShift = 11, kEpochShift = 16, kWordEpochShift = 48;
 constexpr uint64_t kWordMask = (1ull << kWordEpochShift) - 1ull;
@@ -1239,6 +1243,8 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
     // just those; only if one is missing (or near the end, where no tile does sum duty) the group sums behind the
     // missing supergroup words are read as well.
     bool light = g + a.sum_lag + (uint64_t)(NEAR + 1) * kSuperGroups < ex.groups;
+    const bool long_wait = limit >= kRecoverSpins;                  // uniform: bounded by the wall clock instead of a poll count
+    const uint64_t deadline = long_wait ? wall_clock64() + kRecoverTicks : 0ull;
     for (uint32_t spins = 0;; spins++) {
         const uint64_t *watch = nullptr;
         left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super, watch)
@@ -1252,11 +1258,15 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
             if (lane == 0) st_sc1(a.gsum + g, tag | (uint64_t)sum);
             sum_out = true;
         }
-        if (left == 0 || spins >= limit) break;
+        if (left == 0 || spins >= limit || (long_wait && wall_clock64() > deadline)) break;
         __builtin_amdgcn_s_sleep(16);
         // the front is what is missing: cheap looks at one of the missing words until it has appeared
         if (left == 2u && watch != nullptr)
-            while (spins < limit && !word_valid(a, ld_sc1(watch))) { __builtin_amdgcn_s_sleep(8); spins++; }
+            while (spins < limit && !word_valid(a, ld_sc1(watch))) {
+                if (long_wait && wall_clock64() > deadline) break;
+                __builtin_amdgcn_s_sleep(8);
+                spins++;
+            }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: payload loads stay behind the polls
     const bool ok = left == 0;
@@ -1293,10 +1303,12 @@ __device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared 
             uint32_t cw = 0;
             uint64_t unused = 0;
             alive = false;
+            const uint64_t deadline = wall_clock64() + kRecoverTicks;
 #pragma unroll 1
             for (uint32_t spins = 0; spins < kRecoverSpins; spins++) {
                 const uint64_t *nowatch = nullptr;
                 if (!(poll_group<0>(a, ex, gg, lane, 1u, cw, unused, unused, nowatch) & 1u)) { alive = true; break; }
+                if (wall_clock64() > deadline) break;
                 __builtin_amdgcn_s_sleep(16);
             }
             const uint32_t sum = wave_sum_u32(cw & kCountMask);

@@ -250,6 +250,7 @@ __global__ void warm_kernel() {}
 // host side of the shim
 // ---------------------------------------------------------------------------
 thread_local char g_err[512] = "";
+thread_local char g_kernel[160] = "";       // the instantiation the calling thread's last filter call launched (pqps_last_kernel)
 
 // host time spent waiting for a ring slot to become free again (as opposed to time inside runtime calls)
 uint64_t now_ns() {
@@ -294,6 +295,7 @@ struct pqps_ctx {
     uint64_t hand_groups;       // capacity
     uint32_t epoch;             // of the last ID query; 1 .. 65535, then the tagged arrays are zeroed and it starts over
     int parity;                 // ctl half the next ID query uses
+    bool needs_reset;           // a launch failed or a wait ran out: tagged words, ctl and epoch start over before the next ID query
     uint64_t *base_slot;        // gather: first output slot of the running query
     uint64_t *partials;         // workgroup totals of the scan (COUNT / FLAGS modes)
     uint32_t *status_host;      // mapped host word: set by a kernel whose recovery pass gave up
@@ -333,6 +335,13 @@ int zero_tagged_words(pqps_ctx *ctx, hipStream_t s) {
     return PQPS_OK;
 }
 
+// PQPS_EPOCH_START (tests): the epoch a fresh scratch starts from, e.g. 65530 to reach the wrap within a few queries.
+uint32_t first_epoch() {
+    static const char *env = getenv("PQPS_EPOCH_START");
+    const unsigned long v = env ? strtoul(env, nullptr, 10) : 0ul;
+    return v < 0xFFFFul ? (uint32_t)v : 0u;
+}
+
 int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     if (ctx->scratch_steps >= steps && ctx->masks) return PQPS_OK;
     if (ctx->masks) { HIP_TRY(hipDeviceSynchronize()); free_scratch(ctx); }
@@ -354,8 +363,31 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     HIP_TRY(hipMemset(ctx->partials, 0, kPartialSlots * sizeof(uint64_t)));
     HIP_TRY(hipDeviceSynchronize());
     ctx->parity = 0;
-    ctx->epoch = 0;
+    ctx->epoch = first_epoch();
+    ctx->needs_reset = false;
     return PQPS_OK;
+}
+
+// Back to "never written" on the stream the next query runs on: after a failed launch (the ctl half it would have
+// zeroed for its successor still holds tickets) or after a kernel reported that a wait ran out.
+int reset_handoff(pqps_ctx *ctx, hipStream_t s) {
+    int rc = zero_tagged_words(ctx, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->ctl, 0, 2 * kCtlWords * sizeof(uint32_t), s));
+    ctx->parity = 0;
+    ctx->epoch = 0;
+    ctx->needs_reset = false;
+    return PQPS_OK;
+}
+
+// The sticky status word (mapped host memory) is reported ONCE: it is cleared and the hand-off words start over, so
+// the context stays usable after the failed query (include/executeEngine-hip.h promises that to the engine's callers).
+int take_status(pqps_ctx *ctx, const char *who) {
+    const uint32_t st = *(volatile uint32_t *)ctx->status_host;
+    if (st == 0) return PQPS_OK;
+    *(volatile uint32_t *)ctx->status_host = 0;
+    ctx->needs_reset = true;
+    return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this %s are incomplete", st, who);
 }
 
 int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
@@ -464,7 +496,7 @@ eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool mul
 // A scan is "streaming" once the columns it reads outgrow the Infinity Cache (256 MB on MI355X) by
 // a margin: it then uses `nt` loads and a one-shot grid; below that a repeated scan finds part of
 // the table cached and plain loads win.
-constexpr uint64_t kStreamingFootprint = 320ull << 20;
+constexpr uint64_t kStreamingFootprint = 256ull << 20;
 
 bool is_streaming(uint64_t footprint) {
     static const char *force = getenv("PQPS_NT_LOADS");
@@ -496,9 +528,17 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
         a.valu_chain = vc ? 1u : 0u;
         if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, a.streaming != 0, vc)) {   // nullptr unless widths are non-increasing
             if (a.chain != 0 && multi) a.steps_per_iter = (uint32_t)chain_steps((int)w0, (int)w1, (int)w2);
+            const char *mode = MODE == MODE_IDS ? "MODE_IDS" : MODE == MODE_COUNT ? "MODE_COUNT" : "MODE_FLAGS";
+            if (a.chain != 0)
+                snprintf(g_kernel, sizeof g_kernel, "eval_chain_kernel<%s, W0=%u, W1=%u, W2=%u, S=%u, NT=%s, VC=%s>", mode, w0, w1, w2,
+                         a.steps_per_iter ? a.steps_per_iter : 1u, a.streaming ? "true" : "false", vc ? "true" : "false");
+            else
+                snprintf(g_kernel, sizeof g_kernel, "eval_spec_kernel<%s, W0=%u, W1=%u, W2=%u, NT=%s>", mode, w0, w1, w2, a.streaming ? "true" : "false");
             return f;
         }
     }
+    snprintf(g_kernel, sizeof g_kernel, "eval_generic_kernel<%s, GATHER=false, NT=%s>", MODE == MODE_IDS ? "MODE_IDS" : MODE == MODE_COUNT ? "MODE_COUNT" : "MODE_FLAGS",
+             a.streaming ? "true" : "false");
     return a.streaming ? eval_generic_kernel<MODE, false, true> : eval_generic_kernel<MODE, false, false>;
 }
 
@@ -572,10 +612,13 @@ constexpr uint64_t kGatherGridGroups = 32;           // 512 tiles + 128 expander
 
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
-               hipEvent_t done = nullptr) {
-    // `done` (optional) becomes ready when the last kernel of this query has finished.  It rides on
-    // that kernel's own dispatch packet: a separate hipEventRecord would put a barrier packet behind
-    // it and cost the NEXT query on this stream ~7 us of idle queue.
+               hipEvent_t *done_io = nullptr) {
+    // `done_io` (optional): on return *done_io is an event that becomes ready when the last kernel of this query has
+    // finished.  It rides on that kernel's own dispatch packet: a separate hipEventRecord would put a barrier
+    // packet behind it and cost the NEXT query on this stream ~7 us of idle queue.  The caller's event is used
+    // unless the context records timings -- then the recorder's own stop event of this launch is handed back (one
+    // event per dispatch packet).
+    hipEvent_t done = done_io ? *done_io : nullptr;
     const uint64_t steps = (rows + kStepRows - 1) / kStepRows;
     int rc = ensure_scratch(ctx, steps);
     if (rc) return rc;
@@ -592,10 +635,12 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         if (timed) hipExtLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, ctx->ev_start[ctx->timed], ctx->ev_eval[ctx->timed], 0, a);
         else hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, a);
         HIP_TRY(hipGetLastError());
+        if (timed) done = ctx->ev_stop[ctx->timed];              // the end of the query = the end of the reduction
         if (done) hipExtLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, nullptr, done, 0, ctx->partials, out_count);
         else hipLaunchKernelGGL(reduce_totals_kernel, dim3(1), dim3(kBlock), 0, s, ctx->partials, out_count);
         HIP_TRY(hipGetLastError());
-        if (timed) { ctx->stop_is_eval[ctx->timed] = false; HIP_TRY(hipEventRecord(ctx->ev_stop[ctx->timed], s)); ctx->timed++; }
+        if (timed) { ctx->stop_is_eval[ctx->timed] = false; ctx->timed++; }
+        if (done_io) *done_io = done;
         return PQPS_OK;
     }
     if (groups == 0) {
@@ -604,14 +649,16 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         if (done) HIP_TRY(hipEventRecord(done, s));
         return PQPS_OK;
     }
+    if (ctx->needs_reset) { rc = reset_handoff(ctx, s); if (rc) return rc; }
     if (ctx->epoch >= 0xFFFFu) {                                 // the tags are about to repeat: start over from "never written"
         rc = zero_tagged_words(ctx, s);
         if (rc) return rc;
         ctx->epoch = 0;
     }
-    a.epoch = ++ctx->epoch;
+    // epoch and ctl half are committed only once the launch is in the queue: a launch that failed never zeroed the
+    // other half, and the next query must not build on it
+    a.epoch = ctx->epoch + 1u;
     const int half = ctx->parity;
-    ctx->parity ^= 1;
     a.gsum = ctx->gsum; a.ssum = ctx->ssum; a.deferred = ctx->deferred;
     a.ctl = ctx->ctl + half * kCtlWords;
     a.zctl = ctx->ctl + (half ^ 1) * kCtlWords;
@@ -655,12 +702,20 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     hipEvent_t stop = timed ? ctx->ev_eval[ctx->timed] : done;
     if (timed || done) hipExtLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, timed ? ctx->ev_start[ctx->timed] : nullptr, stop, 0, a);
     else hipLaunchKernelGGL(k1, dim3((uint32_t)(main_blocks + lag + slack)), dim3(kBlock), 0, s, a);
-    HIP_TRY(hipGetLastError());
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            ctx->needs_reset = true;
+            return fail(PQPS_EHIP, "filter launch failed: %s", hipGetErrorString(le));
+        }
+    }
+    ctx->epoch = a.epoch;
+    ctx->parity = half ^ 1;
     if (timed) {
         ctx->stop_is_eval[ctx->timed] = true;
         ctx->timed++;
-        if (done) HIP_TRY(hipEventRecord(done, s));
     }
+    if (done_io) *done_io = stop;
     return PQPS_OK;
 }
 
@@ -675,6 +730,7 @@ __attribute__((constructor)) static void pqps_default_hw_queues() { setenv("GPU_
 extern "C" {
 
 const char *pqps_last_error(void) { return g_err; }
+const char *pqps_last_kernel(void) { return g_kernel; }
 
 int pqps_device_count(void) {
     int n = 0;
@@ -719,7 +775,7 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
-    ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0;
+    ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset = false;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
@@ -836,10 +892,7 @@ int pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *
 int pqps_ctx_sync(pqps_ctx *ctx, void *stream) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(pick_stream(ctx, stream)));
-    if (*(volatile uint32_t *)ctx->status_host != 0)
-        return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this context are incomplete",
-                    *(volatile uint32_t *)ctx->status_host);
-    return PQPS_OK;
+    return take_status(ctx, "context");
 }
 
 int pqps_device_info(pqps_ctx *ctx, char *name64, int *compute_units, uint64_t *hbm_bytes) {
@@ -1295,6 +1348,7 @@ struct RcclApi {
     int (*GroupStart)(void);
     int (*GroupEnd)(void);
     int (*CommDestroy)(void *comm);
+    int (*CommAbort)(void *comm);        // optional
     const char *(*GetErrorString)(int rc);
 };
 
@@ -1318,6 +1372,7 @@ int load_rccl(const char *path, RcclApi *api) {
         *sy.slot = dlsym(api->dl, sy.name);
         if (!*sy.slot) return fail(PQPS_EHIP, "%s: symbol %s not found", path, sy.name);
     }
+    *(void **)&api->CommAbort = dlsym(api->dl, "ncclCommAbort");
     return PQPS_OK;
 }
 
@@ -1494,22 +1549,34 @@ int exchange_payload(pqps_exchange *x, uint32_t slot) {
         (void)hipFree(x->merged[slot]);
         x->merged[slot] = nullptr;
         x->merged_cap[slot] = 0;
-        const uint64_t want = total + total / 4 + 4096;
+        uint64_t want = total + total / 4 + 4096;
         hipError_t e = hipMalloc((void **)&x->merged[slot], want * 4);
-        if (e != hipSuccess) return fail(PQPS_ENOMEM, "gathered ID list of %llu entries: %s", (unsigned long long)want, hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipGetLastError(); want = total; e = hipMalloc((void **)&x->merged[slot], want * 4); }   // exactly what the payload needs
+        if (e != hipSuccess) {
+            // This rank cannot receive.  Its peers are about to enter (or already sit in) the same send / recv group and
+            // would wait for this rank's half of it forever: abort the communicator, which ends their calls with an
+            // error instead.  The exchange is dead after this; the caller tears it down.
+            x->merged[slot] = nullptr;
+            (void)hipGetLastError();
+            if (x->world > 1 && x->rccl.CommAbort && x->comm) { (void)x->rccl.CommAbort(x->comm); x->comm = nullptr; }
+            x->state[slot] = kSlotIdle;
+            return fail(PQPS_ENOMEM, "gathered ID list of %llu entries: %s (communicator aborted)", (unsigned long long)want, hipGetErrorString(e));
+        }
         x->merged_cap[slot] = want;
     }
     const uint32_t *mine = x->local + (uint64_t)slot * x->stride + kSlotHeaderWords;
     uint32_t *merged = x->merged[slot];
     int nrc = 0;
-    if (x->world > 1) nrc = x->rccl.GroupStart();
+    // this rank's own part first: a failure here must not leave an opened group behind
     uint64_t displ = 0;
+    for (uint32_t r = 0; r < x->rank; r++) displ += sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];
     const uint64_t own = sizes[x->rank] < x->cap ? sizes[x->rank] : x->cap;
+    if (own) HIP_TRY(hipMemcpyAsync(merged + displ, mine, own * 4, hipMemcpyDeviceToDevice, x->stream));
+    if (x->world > 1) nrc = x->rccl.GroupStart();
+    displ = 0;
     for (uint32_t r = 0; r < x->world && !nrc; r++) {           // mpi:765, as point-to-point pairs
         const uint64_t k = sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];
-        if (r == x->rank) {
-            if (k) HIP_TRY(hipMemcpyAsync(merged + displ, mine, k * 4, hipMemcpyDeviceToDevice, x->stream));
-        } else {
+        if (r != x->rank) {
             if (own) nrc = x->rccl.Send(mine, (size_t)own, kRcclUint32, (int)r, x->comm, x->stream);
             if (!nrc && k) nrc = x->rccl.Recv(merged + displ, (size_t)k, kRcclUint32, (int)r, x->comm, x->stream);
         }
@@ -1589,10 +1656,11 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     // scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.)
     const bool timed = x->ctx->timing;
     if (timed) {
+        hipEvent_t ev = x->scan_done[slot];
         rc = run_filter(x->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
-                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan, x->scan_done[slot]);
+                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, scan, &ev);
         if (rc) return rc;
-        HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(x->stream, ev, 0));
     } else {
         if (!x->ordered) {                                       // what the caller's stream holds (the table, ...) comes first
             HIP_TRY(hipEventRecord(x->joined, scan));
@@ -1600,10 +1668,11 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
             x->ordered = true;
         }
         pqps_ctx *lane = x->child[x->calls % kExchangeLanes];
+        hipEvent_t ev = x->k1_done[slot];
         rc = run_filter(lane, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
-                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, lane->stream, x->k1_done[slot]);
+                        local + kSlotHeaderWords, x->cap, (uint64_t *)local, lane->stream, &ev);
         if (rc) return rc;
-        HIP_TRY(hipStreamWaitEvent(x->stream, x->k1_done[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(x->stream, ev, 0));
     }
     // sizes: mpi:753.  They are needed on the host (send / recv counts): an 8-byte-per-rank all-gather, then a
     // copy into pinned memory behind it
@@ -1637,9 +1706,10 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
+    hipEvent_t ev = x->scan_done[slot];
     if (x->ctx->timing) {
         rc = run_filter(x->ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false, 0,
-                        nullptr, 0, (uint64_t *)local, scan, x->scan_done[slot]);
+                        nullptr, 0, (uint64_t *)local, scan, &ev);
     } else {                                                     // on one of the two scan lanes, as in pqps_exchange_select
         if (!x->ordered) {
             HIP_TRY(hipEventRecord(x->joined, scan));
@@ -1648,10 +1718,10 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
         }
         pqps_ctx *lane = x->child[x->calls % kExchangeLanes];
         rc = run_filter(lane, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false, 0,
-                        nullptr, 0, (uint64_t *)local, lane->stream, x->scan_done[slot]);
+                        nullptr, 0, (uint64_t *)local, lane->stream, &ev);
     }
     if (rc) return rc;
-    HIP_TRY(hipStreamWaitEvent(x->stream, x->scan_done[slot], 0));
+    HIP_TRY(hipStreamWaitEvent(x->stream, ev, 0));
     HIP_TRY(hipMemsetAsync(totals + 1, 0, sizeof(uint64_t), x->stream));
     int nrc = x->rccl.AllReduce(local, totals, 1, kRcclUint64, kRcclSum, x->comm, x->stream);      // mpi:745
     if (nrc) return fail(PQPS_EHIP, "ncclAllReduce: %s", x->rccl.GetErrorString(nrc));
@@ -1697,9 +1767,8 @@ int pqps_exchange_sync(pqps_exchange *x) {
     if (rc) return rc;
     for (uint32_t i = 0; i < kExchangeLanes; i++) {
         HIP_TRY(hipStreamSynchronize(x->child[i]->stream));
-        if (*(volatile uint32_t *)x->child[i]->status_host != 0)
-            return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this exchange are incomplete",
-                        *(volatile uint32_t *)x->child[i]->status_host);
+        const int st = take_status(x->child[i], "exchange");
+        if (st) return st;
     }
     HIP_TRY(hipStreamSynchronize(x->stream));
     x->ordered = false;                                          // the caller may have put new work on its stream meanwhile
@@ -1712,14 +1781,21 @@ int pqps_exchange_sync(pqps_exchange *x) {
 // the next query already queued on ANOTHER stream the dispatcher fills the slots the tail leaves free with that
 // query's scan tiles.  Measured at 100 M rows, per query: S1 60 -> 52.7 us, Q_A 90 -> 73.5, Q_B 107 -> 90.8, a
 // lone u8 column 46 -> 35.1; a third or fourth stream adds nothing (two scans then run side by side for most
-// of their time and their access windows interleave).  Each lane has its own scratch; results keep the caller's
-// ring of output buffers (`depth` of them: buffer k % depth is free again when query k - depth has finished).
+// of their time and their access windows interleave).  Each lane has its own scratch; results go to `depth` SLOTS
+// (the caller's output buffers: slot k is free again when the query that last used it has finished).
+//
+// One lane for large tables: from kInterleaveFromGroups groups on (268 M rows) the expanders run among the scan
+// tiles, the tail is a few percent of the launch, and two launches side by side cost more than the overlap gains
+// (1 G rows: Q_A 736 us per query with two lanes against 690 one at a time, Q_B 960 against 940).  Such queries all
+// go to lane 0, i.e. back to back on one stream; the slots still let the host run ahead.
 struct pqps_qstream {
     pqps_ctx *ctx;
     uint32_t depth, lanes;
     uint64_t seq;
     pqps_ctx **child;                // [lanes] scratch + HIP stream of the queries in flight
-    hipEvent_t *done;                // [depth]
+    hipEvent_t *done;                // [depth] the slots' own events
+    hipEvent_t *ready;               // [depth] what to wait for: the slot's own event, or the timing recorder's stop event of its launch
+    pqps_ctx **ran_on;               // [depth] lane (or the parent context) the slot's query ran on
     hipEvent_t joined;               // what the caller's stream held when the stream of queries began
     bool *used;
     bool ordered;                    // the lanes already wait for the caller's stream
@@ -1733,21 +1809,22 @@ int pqps_qstream_destroy(pqps_qstream *q) {
     for (uint32_t i = 0; i < q->depth; i++)
         if (q->done && q->done[i]) (void)hipEventDestroy(q->done[i]);
     if (q->joined) (void)hipEventDestroy(q->joined);
-    delete[] q->done; delete[] q->child; delete[] q->used;
+    delete[] q->done; delete[] q->ready; delete[] q->ran_on; delete[] q->child; delete[] q->used;
     delete q;
     return PQPS_OK;
 }
 
 int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
     if (!ctx || !out) return fail(PQPS_EINVAL, "NULL argument");
-    if (depth < 2 || depth > 16) return fail(PQPS_EINVAL, "depth %u out of range (2..16)", depth);
+    if (depth < 1 || depth > 64) return fail(PQPS_EINVAL, "depth %u out of range (1..64)", depth);
     pqps_qstream *q = new (std::nothrow) pqps_qstream();
     if (!q) return fail(PQPS_ENOMEM, "out of host memory");
     q->ctx = ctx; q->depth = depth;
     static const int lanes_env = [] { const char *e = getenv("PQPS_QSTREAM_LANES"); return e ? atoi(e) : 0; }();
     q->lanes = lanes_env >= 1 && lanes_env <= 8 ? (uint32_t)lanes_env : 2u;
     if (q->lanes > depth) q->lanes = depth;
-    q->child = new pqps_ctx *[q->lanes](); q->done = new hipEvent_t[depth](); q->used = new bool[depth]();
+    q->child = new pqps_ctx *[q->lanes](); q->done = new hipEvent_t[depth](); q->ready = new hipEvent_t[depth]();
+    q->ran_on = new pqps_ctx *[depth](); q->used = new bool[depth]();
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->joined, hipEventDisableTiming);
     for (uint32_t i = 0; i < depth && e == hipSuccess; i++) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
@@ -1758,71 +1835,127 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
     return PQPS_OK;
 }
 
-int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
-                      const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
-                      void *scan_stream) {
+}  // extern "C"
+
+namespace {
+
+bool one_lane_table(uint64_t n_rows) {
+    static const char *env = getenv("PQPS_QSTREAM_ONE_LANE_ROWS");      // tuning runs
+    const uint64_t from = env ? strtoull(env, nullptr, 10) : kInterleaveFromGroups * (uint64_t)kGroupSteps * kStepRows;
+    return n_rows >= from;
+}
+
+// The slot is the caller's again (a host wait for the query that last used it, normally long satisfied), the lanes
+// come after what the caller's stream holds, and the query gets its lane.
+int qstream_begin(pqps_qstream *q, uint32_t slot, uint64_t n_rows, hipStream_t caller, pqps_ctx **lane) {
+    if (slot >= q->depth) return fail(PQPS_EINVAL, "slot %u >= depth %u", slot, q->depth);
+    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->ready[slot])); q->wait_ns += now_ns() - t0; }
+    if (!q->ordered) {                                           // what the caller's stream holds (the table, ...) comes first
+        HIP_TRY(hipEventRecord(q->joined, caller));
+        for (uint32_t i = 0; i < q->lanes; i++) HIP_TRY(hipStreamWaitEvent(q->child[i]->stream, q->joined, 0));
+        q->ordered = true;
+    }
+    *lane = q->child[one_lane_table(n_rows) ? 0u : (uint32_t)(q->seq % q->lanes)];
+    return PQPS_OK;
+}
+
+int qstream_issue(pqps_qstream *q, uint32_t slot, int mode, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                  const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *scan_stream) {
     if (!q || !out_count) return fail(PQPS_EINVAL, "qstream/out_count is NULL");
-    if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
-    if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
-        return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
+    if (mode == MODE_IDS) {
+        if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
+        if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
+            return fail(PQPS_EINVAL, "row IDs are u32: id_base + n_rows must be <= 2^32");
+    }
     int rc = check_pred(cols, n_cols, pred);
     if (rc) return rc;
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
     a.n_rows = n_rows;
     hipStream_t caller = pick_stream(q->ctx, scan_stream);
+    const eval_fn k1 = mode == MODE_IDS ? pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows) : pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows);
+    pqps_ctx *c = nullptr;
+    hipStream_t s = caller;
     if (q->ctx->timing) {
-        // While the context records timings the query runs whole on the caller's stream with the context's own
-        // scratch, so that the recorded events mean what pqps_ctx_kernel_time documents.
-        return run_filter(q->ctx, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
-                          out_ids, out_capacity, out_count, caller);
+        // While the PARENT context records timings the query runs whole on the caller's stream with the context's
+        // own scratch, one at a time, so that the recorded events mean what pqps_ctx_kernel_time documents.
+        if (slot >= q->depth) return fail(PQPS_EINVAL, "slot %u >= depth %u", slot, q->depth);
+        c = q->ctx;
+    } else {
+        rc = qstream_begin(q, slot, n_rows, caller, &c);
+        if (rc) return rc;
+        s = c->stream;
     }
-    const uint32_t slot = (uint32_t)(q->seq % q->depth), lane = (uint32_t)(q->seq % q->lanes);
-    // the caller's output buffer `slot` is free once the query that last wrote it has finished (a host wait,
-    // `depth` queries back -- normally long satisfied)
-    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->done[slot])); q->wait_ns += now_ns() - t0; }
-    if (!q->ordered) {                                           // what the caller's stream holds (the table, ...) comes first
-        HIP_TRY(hipEventRecord(q->joined, caller));
-        for (uint32_t i = 0; i < q->lanes; i++) HIP_TRY(hipStreamWaitEvent(q->child[i]->stream, q->joined, 0));
-        q->ordered = true;
-    }
-    pqps_ctx *c = q->child[lane];
-    rc = run_filter(c, pick_eval<MODE_IDS>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_IDS, false, id_base,
-                    out_ids, out_capacity, out_count, c->stream, q->done[slot]);
+    hipEvent_t ev = q->done[slot];
+    rc = run_filter(c, k1, a, n_rows, mode, false, id_base, out_ids, out_capacity, out_count, s, &ev);
     if (rc) return rc;
+    q->ready[slot] = ev;
+    q->ran_on[slot] = c;
     q->used[slot] = true;
     q->seq++;
     return PQPS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pqps_qstream_scan_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                           const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *scan_stream) {
+    return qstream_issue(q, slot, MODE_IDS, cols, n_cols, n_rows, id_base, pred, out_ids, out_capacity, out_count, scan_stream);
+}
+
+int pqps_qstream_count_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
+                            const pqps_predicate *pred, uint64_t *out_count, void *scan_stream) {
+    return qstream_issue(q, slot, MODE_COUNT, cols, n_cols, n_rows, 0, pred, nullptr, 0, out_count, scan_stream);
+}
+
+int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
+                      const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count,
+                      void *scan_stream) {
+    if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    return qstream_issue(q, (uint32_t)(q->seq % q->depth), MODE_IDS, cols, n_cols, n_rows, id_base, pred, out_ids, out_capacity, out_count, scan_stream);
 }
 
 // COUNT(*) through the same two lanes (the scan + its one-workgroup reduction whole on a lane: one query's ramp and
 // drain under the other's scan -- S1 58 -> 48 us, Q_A 67 -> 58, a lone u8 column 22 -> 15.5 us per query at 100 M rows).
 int pqps_qstream_count(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                        const pqps_predicate *pred, uint64_t *out_count, void *scan_stream) {
-    if (!q || !out_count) return fail(PQPS_EINVAL, "qstream/out_count is NULL");
-    int rc = check_pred(cols, n_cols, pred);
+    if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    return qstream_issue(q, (uint32_t)(q->seq % q->depth), MODE_COUNT, cols, n_cols, n_rows, 0, pred, nullptr, 0, out_count, scan_stream);
+}
+
+// A query that is more than one filter call (index probes + gather filters, flag passes before the last pass): the
+// caller gets the lane the slot's query runs on, issues its calls there, and marks the end.
+int pqps_qstream_lane(pqps_qstream *q, uint32_t slot, uint64_t n_rows, void *scan_stream, pqps_ctx **lane_ctx, void **lane_stream) {
+    if (!q || !lane_ctx || !lane_stream) return fail(PQPS_EINVAL, "NULL argument");
+    pqps_ctx *c = nullptr;
+    int rc = qstream_begin(q, slot, n_rows, pick_stream(q->ctx, scan_stream), &c);
     if (rc) return rc;
-    EvalArgs a;
-    fill_args(a, cols, n_cols, pred);
-    a.n_rows = n_rows;
-    hipStream_t caller = pick_stream(q->ctx, scan_stream);
-    if (q->ctx->timing)
-        return run_filter(q->ctx, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false, 0,
-                          nullptr, 0, out_count, caller);
-    const uint32_t slot = (uint32_t)(q->seq % q->depth), lane = (uint32_t)(q->seq % q->lanes);
-    if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->done[slot])); q->wait_ns += now_ns() - t0; }
-    if (!q->ordered) {
-        HIP_TRY(hipEventRecord(q->joined, caller));
-        for (uint32_t i = 0; i < q->lanes; i++) HIP_TRY(hipStreamWaitEvent(q->child[i]->stream, q->joined, 0));
-        q->ordered = true;
-    }
-    pqps_ctx *c = q->child[lane];
-    rc = run_filter(c, pick_eval<MODE_COUNT>(cols, n_cols, pred, a, n_rows), a, n_rows, MODE_COUNT, false, 0,
-                    nullptr, 0, out_count, c->stream, q->done[slot]);
-    if (rc) return rc;
-    q->used[slot] = true;
+    q->ran_on[slot] = c;
     q->seq++;
+    *lane_ctx = c;
+    *lane_stream = (void *)c->stream;
     return PQPS_OK;
+}
+
+int pqps_qstream_mark(pqps_qstream *q, uint32_t slot) {
+    if (!q || slot >= q->depth || !q->ran_on[slot]) return fail(PQPS_EINVAL, "slot %u has no query", slot);
+    (void)hipSetDevice(q->ctx->device);
+    HIP_TRY(hipEventRecord(q->done[slot], q->ran_on[slot]->stream));
+    q->ready[slot] = q->done[slot];
+    q->used[slot] = true;
+    return PQPS_OK;
+}
+
+// Host wait for ONE slot's query (a stream synchronise would also wait for the queries issued after it).  May be
+// called from another thread than the one that issues.
+int pqps_qstream_wait(pqps_qstream *q, uint32_t slot) {
+    if (!q || slot >= q->depth) return fail(PQPS_EINVAL, "slot out of range");
+    if (!q->used[slot]) return PQPS_OK;
+    (void)hipSetDevice(q->ctx->device);
+    HIP_TRY(hipEventSynchronize(q->ready[slot]));
+    return take_status(q->ran_on[slot], "query");
 }
 
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset) {
@@ -1834,14 +1967,48 @@ uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset) {
 
 int pqps_qstream_sync(pqps_qstream *q) {
     if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    (void)hipSetDevice(q->ctx->device);
     for (uint32_t i = 0; i < q->lanes; i++) {
         HIP_TRY(hipStreamSynchronize(q->child[i]->stream));
-        if (*(volatile uint32_t *)q->child[i]->status_host != 0)
-            return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this query stream are incomplete",
-                        *(volatile uint32_t *)q->child[i]->status_host);
+        const int st = take_status(q->child[i], "query stream");
+        if (st) return st;
     }
     q->ordered = false;                                          // the caller may have put new work on its stream meanwhile
     return PQPS_OK;
 }
+
+// Per-launch timing of the queries AS THEY RUN IN THE STREAM (two in flight): the lanes' own recorders.  The
+// events ride on the dispatch packets, so recording does not change how the launches overlap.
+int pqps_qstream_set_timing(pqps_qstream *q, int enable) {
+    if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    for (uint32_t i = 0; i < q->lanes; i++) { const int rc = pqps_ctx_set_timing(q->child[i], enable); if (rc) return rc; }
+    return PQPS_OK;
+}
+
+int pqps_qstream_kernel_time(pqps_qstream *q, double *eval_ms, double *total_ms, int *launches) {
+    if (!q || !eval_ms || !total_ms || !launches) return fail(PQPS_EINVAL, "NULL argument");
+    *eval_ms = 0.0; *total_ms = 0.0; *launches = 0;
+    for (uint32_t i = 0; i < q->lanes; i++) {
+        double e = 0.0, t = 0.0; int k = 0;
+        const int rc = pqps_ctx_kernel_time(q->child[i], &e, &t, &k);
+        if (rc) return rc;
+        *eval_ms += e; *total_ms += t; *launches += k;
+    }
+    return PQPS_OK;
+}
+
+// Peer copy between two contexts' devices (or inside one device), asynchronous on `stream` of the DESTINATION
+// context (NULL: its own).  What the one-process engine gathers its shards' results with (xGMI DMA; the one-process
+// counterpart of the send / recv pairs of pqps_exchange).
+int pqps_copy_peer(pqps_ctx *dst_ctx, void *dst, pqps_ctx *src_ctx, const void *src, size_t bytes, void *stream) {
+    if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return fail(PQPS_EINVAL, "NULL argument");
+    if (bytes == 0) return PQPS_OK;
+    hipStream_t s = pick_stream(dst_ctx, stream);
+    if (dst_ctx->device == src_ctx->device) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device, bytes, s));
+    return PQPS_OK;
+}
+
+int pqps_ctx_device(pqps_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 }  // extern "C"

@@ -293,7 +293,7 @@ static void hip_die(const char *what) {
 void hipSchemaOfTable(const struct hipTable *t, struct hipSchema *s) {
     memset(s, 0, sizeof *s);
     for (int c = 0; c < HIPCOL_COUNT; c++) {
-        s->col[c].present = t->col[c].data != NULL || t->n_rows == 0;
+        s->col[c].present = t->col[c].data != NULL || t->n_rows == 0 || (k_kind[c] == HIPKIND_DICT && t->dict[c].count == 1);
         s->col[c].kind = k_kind[c];
         s->col[c].width = t->col[c].width;
         s->col[c].dict_count = t->dict[c].count;
@@ -426,27 +426,84 @@ static void shard_range(size_t n, int parts, int s, size_t *start, size_t *count
     *count = base + ((size_t)s < rem ? 1 : 0);
 }
 
-/* Device side of one shard: rows [row0, row0 + count) of the staged columns.  Capacity leaves head-room so
- * that INSERT appends in place; the rows past the last one are zero (the filter reads whole 1024-row steps). */
-static void shard_upload(struct hipTable *sh, pqps_ctx *ctx, const struct hipTable *widths, void *const *stage,
-                         size_t row0, size_t count) {
+/* Result buffers of one lane of one shard (`copy`: a context of its own for the lane's downloads; NULL for the
+ * table's own buffers). */
+static void lane_alloc(struct hipTable *sh, struct hipLane *L, bool own_context) {
+    memset(L, 0, sizeof *L);
+    L->capacity_ids = sh->capacity_rows;
+    if (pqps_malloc(sh->ctx, L->capacity_ids * sizeof(uint32_t), (void **)&L->ids_dev) != PQPS_OK) hip_die("result allocation");
+    if (pqps_malloc(sh->ctx, 8 * sizeof(uint64_t), (void **)&L->count_dev) != PQPS_OK) hip_die("counter allocation");
+    if (own_context && pqps_ctx_create(pqps_ctx_device(sh->ctx), &L->copy) != PQPS_OK) hip_die("lane context");
+}
+
+static void lane_free(struct hipTable *sh, struct hipLane *L) {
+    if (L->ids_dev) pqps_free(sh->ctx, L->ids_dev);
+    if (L->count_dev) pqps_free(sh->ctx, L->count_dev);
+    if (L->merged_dev) pqps_free(sh->ctx, L->merged_dev);
+    if (L->copy) pqps_ctx_destroy(L->copy);
+    memset(L, 0, sizeof *L);
+}
+
+static int engine_lanes(void) {
+    const char *env = getenv("PQPS_ENGINE_LANES");
+    const int n = env ? atoi(env) : 4;
+    return n < 1 ? 1 : (n > HIP_MAX_LANES ? HIP_MAX_LANES : n);
+}
+
+/* Engine tables: `n_lanes` queries in flight per shard -- result buffers each, and a query stream with as many slots. */
+static void shard_lanes_create(struct hipTable *sh, int n_lanes) {
+    sh->n_lanes = n_lanes;
+    for (int k = 0; k < n_lanes; k++) lane_alloc(sh, &sh->lane[k], true);
+    if (pqps_qstream_create(sh->ctx, (uint32_t)n_lanes, &sh->qs) != PQPS_OK) hip_die("query stream");
+}
+
+/* Buffers of one shard for rows [row0, row0 + count): capacity leaves head-room so that INSERT appends in place; the
+ * rows past the last one are zero (the filter reads whole 1024-row steps). */
+static void shard_alloc(struct hipTable *sh, pqps_ctx *ctx, const struct hipTable *widths, size_t row0, size_t count) {
     sh->ctx = ctx;
     sh->n_rows = count;
     sh->row0 = row0;
     sh->capacity_rows = (count + count / 16 + PQPS_TILE_ROWS) / PQPS_TILE_ROWS * PQPS_TILE_ROWS;
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         const uint32_t width = widths->col[c].width;
+        sh->col[c].data = NULL;
+        sh->col[c].width = width;
+        if (width == 0) continue;                                 /* single-valued string column */
         void *dev = NULL;
         if (pqps_malloc(ctx, sh->capacity_rows * width, &dev) != PQPS_OK) hip_die("column allocation");
-        if (pqps_memset(ctx, dev, 0, sh->capacity_rows * width, NULL) != PQPS_OK) hip_die("column clear");
-        if (count && pqps_upload(ctx, dev, (const char *)stage[c] + row0 * width, count * width, NULL) != PQPS_OK) hip_die("column upload");
+        /* only the tail needs clearing when the caller fills rows [0, count) */
+        if (pqps_memset(ctx, (char *)dev + count * width, 0, (sh->capacity_rows - count) * width, NULL) != PQPS_OK) hip_die("column clear");
         sh->col[c].data = dev;
-        sh->col[c].width = width;
     }
-    sh->capacity_ids = sh->capacity_rows;
-    if (pqps_malloc(ctx, sh->capacity_ids * sizeof(uint32_t), (void **)&sh->ids_dev) != PQPS_OK) hip_die("result allocation");
-    if (pqps_malloc(ctx, 8 * sizeof(uint64_t), (void **)&sh->count_dev) != PQPS_OK) hip_die("counter allocation");
+    lane_alloc(sh, &sh->own, false);
     if (pqps_ctx_reserve(ctx, sh->capacity_rows) != PQPS_OK) hip_die("filter scratch allocation");   /* not inside the first query */
+}
+
+/* Device side of one shard: rows [row0, row0 + count) of the staged columns. */
+static void shard_upload(struct hipTable *sh, pqps_ctx *ctx, const struct hipTable *widths, void *const *stage,
+                         size_t row0, size_t count) {
+    shard_alloc(sh, ctx, widths, row0, count);
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        const uint32_t width = widths->col[c].width;
+        if (count && width && pqps_upload(ctx, (void *)sh->col[c].data, (const char *)stage[c] + row0 * width, count * width, NULL) != PQPS_OK)
+            hip_die("column upload");
+    }
+}
+
+/* The shard structs of a table over `n_shards` contexts (shard 0 = the table itself). */
+static void table_make_shards(struct hipTable *t, int n_shards) {
+    t->n_shards = 0;
+    t->shard = NULL;
+    if (n_shards > 1) {
+        t->shard = calloc((size_t)n_shards, sizeof *t->shard);
+        if (!t->shard) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+        t->n_shards = n_shards;
+        t->shard[0] = t;
+        for (int s = 1; s < n_shards; s++) {
+            t->shard[s] = calloc(1, sizeof **t->shard);
+            if (!t->shard[s]) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+        }
+    }
 }
 
 static void table_fill(struct hipTable *t, pqps_ctx *const *ctxs, int n_shards, struct hipContextFuture *future,
@@ -476,24 +533,11 @@ static void table_fill(struct hipTable *t, pqps_ctx *const *ctxs, int n_shards, 
         ctxs = future->ctx;
         n_shards = future->n;
     }
-    t->n_shards = 0;
-    t->shard = NULL;
-    if (n_shards > 1) {
-        t->shard = calloc((size_t)n_shards, sizeof *t->shard);
-        if (!t->shard) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
-        t->n_shards = n_shards;
-        t->shard[0] = t;
-    }
+    table_make_shards(t, n_shards);
     for (int s = 0; s < n_shards; s++) {
-        struct hipTable *sh = t;
-        if (s > 0) {
-            sh = calloc(1, sizeof *sh);
-            if (!sh) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
-            t->shard[s] = sh;
-        }
         size_t row0, count;
         shard_range(n, n_shards, s, &row0, &count);
-        shard_upload(sh, ctxs[s], t, job.stage, row0, count);
+        shard_upload(hipTableShard(t, s), ctxs[s], t, job.stage, row0, count);
     }
     for (int c = 0; c < HIPCOL_COUNT; c++) free(job.stage[c]);
 }
@@ -510,16 +554,98 @@ static void dictionary_free(struct hipDictionary *d) {
     memset(d, 0, sizeof *d);
 }
 
+/* Readers (SELECT / COUNT, each on a lane of its own) and writers (INSERT / DELETE / index creation, alone).  A
+ * reader may end on another thread than it began on (asynchronous tickets), which a pthread rwlock does not allow. */
 struct hipLocks {
-    pthread_rwlock_t rows;
-    pthread_mutex_t device;
+    pthread_mutex_t m;
+    pthread_cond_t cv;
+    int readers, writer, writers_waiting;
+    unsigned busy_lanes;                 /* bit k: lane k is taken */
+    int n_lanes;
+    pthread_mutex_t issue;               /* issuing calls on the shards' query streams */
 };
 
-void hipTableLockShared(struct hipTable *t) { if (t && t->locks) pthread_rwlock_rdlock(&t->locks->rows); }
-void hipTableLockExclusive(struct hipTable *t) { if (t && t->locks) pthread_rwlock_wrlock(&t->locks->rows); }
-void hipTableUnlock(struct hipTable *t) { if (t && t->locks) pthread_rwlock_unlock(&t->locks->rows); }
-void hipTableLockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_lock(&t->locks->device); }
-void hipTableUnlockDevice(struct hipTable *t) { if (t && t->locks) pthread_mutex_unlock(&t->locks->device); }
+static struct hipLocks *locks_create(int n_lanes) {
+    struct hipLocks *l = calloc(1, sizeof *l);
+    if (!l || pthread_mutex_init(&l->m, NULL) != 0 || pthread_cond_init(&l->cv, NULL) != 0 || pthread_mutex_init(&l->issue, NULL) != 0) {
+        perror("Failed to create engine locks");
+        exit(EXIT_FAILURE);
+    }
+    l->n_lanes = n_lanes;
+    return l;
+}
+
+static void locks_destroy(struct hipLocks *l) {
+    if (!l) return;
+    pthread_mutex_destroy(&l->m);
+    pthread_cond_destroy(&l->cv);
+    pthread_mutex_destroy(&l->issue);
+    free(l);
+}
+
+void hipTableLockShared(struct hipTable *t) {
+    if (!t || !t->locks) return;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    while (l->writer || l->writers_waiting) pthread_cond_wait(&l->cv, &l->m);      /* writers first: a stream of readers cannot starve them */
+    l->readers++;
+    pthread_mutex_unlock(&l->m);
+}
+
+void hipTableUnlockShared(struct hipTable *t) {
+    if (!t || !t->locks) return;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    if (--l->readers == 0) pthread_cond_broadcast(&l->cv);
+    pthread_mutex_unlock(&l->m);
+}
+
+void hipTableLockExclusive(struct hipTable *t) {
+    if (!t || !t->locks) return;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    l->writers_waiting++;
+    while (l->writer || l->readers) pthread_cond_wait(&l->cv, &l->m);
+    l->writers_waiting--;
+    l->writer = 1;
+    pthread_mutex_unlock(&l->m);
+}
+
+void hipTableUnlockExclusive(struct hipTable *t) {
+    if (!t || !t->locks) return;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    l->writer = 0;
+    pthread_cond_broadcast(&l->cv);
+    pthread_mutex_unlock(&l->m);
+}
+
+int hipTableAcquireLane(struct hipTable *t) {
+    if (!t || !t->locks || t->locks->n_lanes == 0) return -1;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    int k;
+    for (;;) {
+        for (k = 0; k < l->n_lanes; k++) if (!(l->busy_lanes & (1u << k))) break;
+        if (k < l->n_lanes) break;
+        pthread_cond_wait(&l->cv, &l->m);
+    }
+    l->busy_lanes |= 1u << k;
+    pthread_mutex_unlock(&l->m);
+    return k;
+}
+
+void hipTableReleaseLane(struct hipTable *t, int lane) {
+    if (!t || !t->locks || lane < 0) return;
+    struct hipLocks *l = t->locks;
+    pthread_mutex_lock(&l->m);
+    l->busy_lanes &= ~(1u << lane);
+    pthread_cond_broadcast(&l->cv);
+    pthread_mutex_unlock(&l->m);
+}
+
+void hipTableLockIssue(struct hipTable *t) { if (t && t->locks) pthread_mutex_lock(&t->locks->issue); }
+void hipTableUnlockIssue(struct hipTable *t) { if (t && t->locks) pthread_mutex_unlock(&t->locks->issue); }
 
 /* Device buffers of one shard. */
 static void shard_release(struct hipTable *sh, int n_indexes) {
@@ -535,10 +661,10 @@ static void shard_release(struct hipTable *sh, int n_indexes) {
         free(sh->index);
         sh->index = NULL;
     }
-    if (sh->ids_dev) pqps_free(sh->ctx, sh->ids_dev);
-    if (sh->count_dev) pqps_free(sh->ctx, sh->count_dev);
-    sh->ids_dev = NULL;
-    sh->count_dev = NULL;
+    if (sh->qs) { pqps_qstream_destroy(sh->qs); sh->qs = NULL; }
+    for (int k = 0; k < sh->n_lanes; k++) lane_free(sh, &sh->lane[k]);
+    sh->n_lanes = 0;
+    lane_free(sh, &sh->own);
 }
 
 /* Frees what the table owns on its devices, its dictionaries and its peer shards -- not the struct
@@ -558,11 +684,7 @@ static void table_release(struct hipTable *t, int n_indexes) {
 void hipTableFree(struct hipTable *t, int n_indexes) {
     if (!t) return;
     table_release(t, n_indexes);
-    if (t->locks) {
-        pthread_rwlock_destroy(&t->locks->rows);
-        pthread_mutex_destroy(&t->locks->device);
-        free(t->locks);
-    }
+    locks_destroy(t->locks);
     free(t);
 }
 
@@ -572,6 +694,7 @@ static bool build_index(struct engineS *engine, struct hipTable *t, int slot) {
     memset(ix, 0, sizeof *ix);
     ix->column = hipColumnId(engine->indexed_attributes[slot]);
     if (ix->column < 0) return false;
+    if (!t->col[ix->column].data) { ix->column = -1; return false; }      /* a single-valued column has no buffer to sort */
     ix->key_kind = k_kind[ix->column] == HIPKIND_I32 ? 1 : 0;
     const size_t n = t->n_rows ? t->n_rows : 1;
     if (pqps_malloc(t->ctx, n * sizeof(uint32_t), (void **)&ix->perm_dev) != PQPS_OK) hip_die("index allocation");
@@ -607,6 +730,13 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
     return ok;
 }
 
+/* What makes a table an ENGINE's table: query lanes on every shard and the locks. */
+static void table_make_engine(struct hipTable *t) {
+    const int n_lanes = engine_lanes();
+    for (int s = 0; s < hipTableShards(t); s++) shard_lanes_create(hipTableShard(t, s), n_lanes);
+    if (!t->locks) t->locks = locks_create(n_lanes);
+}
+
 bool buildDeviceTableHIP(struct engineS *engine) {
     struct hipContextFuture *f = hipBeginContextHIP();
     const bool ok = buildDeviceTableOnHIP(engine, f);
@@ -628,11 +758,7 @@ bool buildDeviceTableOnHIP(struct engineS *engine, struct hipContextFuture *futu
     } else {
         t->row_capacity = 0;                                       /* no block yet: the first INSERT allocates one */
     }
-    t->locks = calloc(1, sizeof *t->locks);
-    if (!t->locks || pthread_rwlock_init(&t->locks->rows, NULL) != 0 || pthread_mutex_init(&t->locks->device, NULL) != 0) {
-        perror("Failed to create engine locks");
-        exit(EXIT_FAILURE);
-    }
+    table_make_engine(t);
     engine->record_block = t;
     return true;
 }
@@ -653,6 +779,7 @@ void rebuildDeviceTableHIP(struct engineS *engine) {
     t->row_block = block;
     t->row_capacity = row_capacity;
     t->locks = locks;
+    table_make_engine(t);
     for (int s = 0; s < n_shards && engine->num_indexes > 0; s++) {
         struct hipTable *sh = hipTableShard(t, s);
         sh->index = calloc((size_t)engine->num_indexes, sizeof *sh->index);
@@ -666,6 +793,8 @@ static void rebuild_indexes(struct engineS *engine, struct hipTable *t) {
     for (int i = 0; i < engine->num_indexes; i++) {
         if (t->index[i].perm_dev) pqps_free(t->ctx, t->index[i].perm_dev);
         if (t->index[i].keys_dev) pqps_free(t->ctx, t->index[i].keys_dev);
+        t->index[i].perm_dev = NULL;
+        t->index[i].keys_dev = NULL;
         build_index(engine, t, i);
     }
 }
@@ -675,13 +804,14 @@ static void rebuild_indexes(struct engineS *engine, struct hipTable *t) {
  * above that rank are bumped on every shard (order-preserving codes stay order-preserving).
  * Falls back to a full rebuild only when a column has to change its code width or the
  * head-room is used up. */
-void appendRowDeviceTableHIP(struct engineS *engine) {
+bool appendRowDeviceTableHIP(struct engineS *engine, const record *r) {
     struct hipTable *t = engine->record_block;
     const int n_shards = hipTableShards(t);
     struct hipTable *last = hipTableShard(t, n_shards - 1);
     const size_t n = (size_t)engine->num_records;               /* rows after the insert */
-    if (n == 0 || n - 1 != last->row0 + last->n_rows || last->n_rows + 1 > last->capacity_rows) { rebuildDeviceTableHIP(engine); return; }
-    const record *r = engine->all_records[n - 1];
+    /* what only a rebuild from the host rows can do: a device-only engine cannot */
+#define REBUILD_OR_FAIL() do { if (t->device_only) return false; rebuildDeviceTableHIP(engine); return true; } while (0)
+    if (n == 0 || n - 1 != last->row0 + last->n_rows || last->n_rows + 1 > last->capacity_rows) REBUILD_OR_FAIL();
     /* first pass: would any dictionary outgrow its code width? */
     int pos[HIPCOL_COUNT], present[HIPCOL_COUNT];
     for (int c = 0; c < HIPCOL_COUNT; c++) {
@@ -692,9 +822,10 @@ void appendRowDeviceTableHIP(struct engineS *engine) {
         while (l < h) { const int m = l + (h - l) / 2; if (strcmp(d->values[m], s) < 0) l = m + 1; else h = m; }
         pos[c] = l;
         present[c] = l < d->count && strcmp(d->values[l], s) == 0;
-        const uint64_t limit = t->col[c].width == 1 ? 256 : t->col[c].width == 2 ? 65536 : 0xFFFFFFFFull;
-        if (!present[c] && (uint64_t)d->count + 1 > limit) { rebuildDeviceTableHIP(engine); return; }
+        const uint64_t limit = t->col[c].width == 0 ? 1 : t->col[c].width == 1 ? 256 : t->col[c].width == 2 ? 65536 : 0xFFFFFFFFull;
+        if (!present[c] && (uint64_t)d->count + 1 > limit) REBUILD_OR_FAIL();
     }
+#undef REBUILD_OR_FAIL
     bool bumped = false;
     for (int c = 0; c < HIPCOL_COUNT; c++) {
         const uint32_t w = t->col[c].width;
@@ -725,11 +856,12 @@ void appendRowDeviceTableHIP(struct engineS *engine) {
             break;
         }
         }
-        if (pqps_upload(last->ctx, (char *)last->col[c].data + last->n_rows * w, &value, w, NULL) != PQPS_OK) hip_die("row upload");
+        if (w && pqps_upload(last->ctx, (char *)last->col[c].data + last->n_rows * w, &value, w, NULL) != PQPS_OK) hip_die("row upload");
     }
     last->n_rows += 1;
     for (int s = 0; s < n_shards; s++)                          /* shifted codes are keys of the other shards' indexes too */
         if (bumped || s == n_shards - 1) rebuild_indexes(engine, hipTableShard(t, s));
+    return true;
 }
 
 /* DELETE: drops the flagged rows from the device columns of every shard in place and re-sorts the
@@ -740,7 +872,10 @@ void compactDeviceTableHIP(struct engineS *engine, uint8_t *const *delete_flags_
     for (int s = 0; s < hipTableShards(t); s++) {
         struct hipTable *sh = hipTableShard(t, s);
         uint64_t kept = 0;
-        if (pqps_compact_rows(sh->ctx, sh->col, HIPCOL_COUNT, sh->n_rows, delete_flags_dev[s], &kept, NULL) != PQPS_OK)
+        pqps_column cols[HIPCOL_COUNT];
+        uint32_t n_cols = 0;
+        for (int c = 0; c < HIPCOL_COUNT; c++) if (sh->col[c].data) cols[n_cols++] = sh->col[c];      /* (single-valued columns have no buffer) */
+        if (pqps_compact_rows(sh->ctx, cols, n_cols, sh->n_rows, delete_flags_dev[s], &kept, NULL) != PQPS_OK)
             hip_die("row compaction");
         const bool changed = kept != sh->n_rows || sh->row0 != total;
         sh->n_rows = kept;
@@ -775,4 +910,181 @@ void destroyDeviceTableHIP(struct engineS *engine) {
                 (double)(t2.tv_sec - t1.tv_sec) * 1e3 + (double)(t2.tv_nsec - t1.tv_nsec) * 1e-6, n_shards,
                 (double)(t3.tv_sec - t2.tv_sec) * 1e3 + (double)(t3.tv_nsec - t2.tv_nsec) * 1e-6);
     engine->record_block = NULL;
+}
+
+/* ---- engines over device-resident columns (no host rows) ------------------------------------------------ */
+
+static int dictionary_from_strings(struct hipDictionary *d, const char *const *values, int count) {
+    size_t bytes = 0;
+    for (int i = 0; i < count; i++) {
+        if (!values[i]) return -1;
+        if (i > 0 && strcmp(values[i - 1], values[i]) >= 0) return -1;         /* ascending strcmp order, no duplicates */
+        bytes += strlen(values[i]) + 1;
+    }
+    d->count = count;
+    d->storage = malloc(bytes ? bytes : 1);
+    d->storage_bytes = bytes;
+    d->values = malloc((size_t)(count > 0 ? count : 1) * sizeof *d->values);
+    if (!d->storage || !d->values) return -1;
+    char *w = d->storage;
+    for (int i = 0; i < count; i++) {
+        const size_t l = strlen(values[i]) + 1;
+        memcpy(w, values[i], l);
+        d->values[i] = w;
+        w += l;
+    }
+    return 0;
+}
+
+static const uint32_t k_numeric_width[HIPCOL_COUNT] = { 8, 0, 0, 0, 4, 0, 1, 0, 4, 0, 0, 4 };
+
+/* The table struct of a device-only engine with its dictionaries and column widths; the shards' buffers exist
+ * (allocated, tails cleared) and wait to be filled. */
+static struct hipTable *columns_table(unsigned long long num_rows, const struct hipColumnData *columns, pqps_ctx ***ctxs_out, int *n_shards_out) {
+    struct hipContextFuture *f = hipBeginContextHIP();
+    struct hipTable *t = calloc(1, sizeof *t);
+    if (!t) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        const struct hipColumnData *cd = &columns[c];
+        if (k_kind[c] != HIPKIND_DICT) {
+            if (cd->width != k_numeric_width[c] || (!cd->values && num_rows)) {
+                fprintf(stderr, "HIP engine: column %d: a numeric column of %u bytes per row is expected\n", c, k_numeric_width[c]);
+                exit(EXIT_FAILURE);
+            }
+            t->col[c].width = cd->width;
+            continue;
+        }
+        if (cd->dictionary_count < 0 || (cd->dictionary_count > 0 && !cd->dictionary) ||
+            dictionary_from_strings(&t->dict[c], cd->dictionary, cd->dictionary_count) != 0) {
+            fprintf(stderr, "HIP engine: column %d: the dictionary must be %d distinct strings in ascending strcmp order\n", c, cd->dictionary_count);
+            exit(EXIT_FAILURE);
+        }
+        if (!cd->values && cd->dictionary_count == 1) { t->col[c].width = 0; continue; }      /* every row carries the one value */
+        const uint64_t room = cd->width == 1 ? 256 : cd->width == 2 ? 65536 : cd->width == 4 ? 0x100000000ull : 0;
+        if (room == 0 || (uint64_t)cd->dictionary_count > room || (!cd->values && num_rows)) {
+            fprintf(stderr, "HIP engine: column %d: codes of %u bytes cannot number %d dictionary values\n", c, cd->width, cd->dictionary_count);
+            exit(EXIT_FAILURE);
+        }
+        t->col[c].width = cd->width;
+    }
+    await_contexts(f);
+    pqps_ctx **ctxs = malloc((size_t)f->n * sizeof *ctxs);
+    if (!ctxs) { perror("Failed to allocate memory for device table"); exit(EXIT_FAILURE); }
+    for (int s = 0; s < f->n; s++) ctxs[s] = f->ctx[s];
+    const int n_shards = f->n;
+    free(f);
+    table_make_shards(t, n_shards);
+    for (int s = 0; s < n_shards; s++) {
+        size_t row0, count;
+        shard_range((size_t)num_rows, n_shards, s, &row0, &count);
+        shard_alloc(hipTableShard(t, s), ctxs[s], t, row0, count);
+    }
+    t->device_only = 1;
+    *ctxs_out = ctxs;
+    *n_shards_out = n_shards;
+    return t;
+}
+
+bool buildDeviceTableFromColumnsHIP(struct engineS *engine, unsigned long long num_rows, const struct hipColumnData *columns) {
+    pqps_ctx **ctxs = NULL;
+    int n_shards = 0;
+    struct hipTable *t = columns_table(num_rows, columns, &ctxs, &n_shards);
+    for (int s = 0; s < n_shards; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        for (int c = 0; c < HIPCOL_COUNT; c++) {
+            const uint32_t w = sh->col[c].width;
+            if (!w || !sh->n_rows) continue;
+            const char *src = (const char *)columns[c].values + sh->row0 * w;
+            const int rc = columns[c].on_device ? pqps_copy_peer(sh->ctx, (void *)sh->col[c].data, ctxs[0], src, sh->n_rows * w, NULL)
+                                                : pqps_upload(sh->ctx, (void *)sh->col[c].data, src, sh->n_rows * w, NULL);
+            if (rc != PQPS_OK) hip_die("column copy");
+        }
+        if (pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) hip_die("column copy");
+    }
+    free(ctxs);
+    table_make_engine(t);
+    engine->record_block = t;
+    return true;
+}
+
+/* Dictionaries of the synthetic table: the strings behind the codes of pqps_synth_generate (include/pqps_hip.h:
+ * shell_code = rank in {bash, fish, sh, zsh}, user_code = user_id - 1000, host_code = rank among 16 host names,
+ * base_code = rank among 111 base commands); raw_command, timestamp and working_directory carry one value. */
+static const char *const k_synth_shells[4] = { "bash", "fish", "sh", "zsh" };
+static const char *const k_synth_hosts[16] = {
+    "cs-lab-01", "cs-lab-02", "labpc-01", "labpc-02", "labpc-03", "labpc-04", "labpc-05", "labpc-06", "labpc-07", "labpc-08",
+    "labpc-09", "labpc-10", "personal-laptop", "remote-ssh-01", "vm-ubuntu-01", "vm-ubuntu-02"
+};
+static const char *const k_synth_raw[1] = { "cmd" };
+static const char *const k_synth_time[1] = { "2025-01-01T00:00:00.000Z" };
+static const char *const k_synth_dir[1] = { "/home/u" };
+static char k_synth_user_text[PQPS_SYNTH_USERS][12], k_synth_base_text[111][8];
+static const char *k_synth_users[PQPS_SYNTH_USERS], *k_synth_bases[111];
+static pthread_once_t k_synth_once = PTHREAD_ONCE_INIT;
+
+static void synth_names_init(void) {
+    for (int i = 0; i < PQPS_SYNTH_USERS; i++) { snprintf(k_synth_user_text[i], sizeof k_synth_user_text[i], "student%d", 1000 + i); k_synth_users[i] = k_synth_user_text[i]; }
+    for (int i = 0; i < 111; i++) { snprintf(k_synth_base_text[i], sizeof k_synth_base_text[i], "cmd%03d", i); k_synth_bases[i] = k_synth_base_text[i]; }
+}
+
+const char *const *hipSyntheticDictionary(int column, int *count) {
+    pthread_once(&k_synth_once, synth_names_init);
+    int n = 0;
+    const char *const *d = NULL;
+    switch (column) {
+    case HIPCOL_RAW_COMMAND: d = k_synth_raw; n = 1; break;
+    case HIPCOL_BASE_COMMAND: d = k_synth_bases; n = 111; break;
+    case HIPCOL_SHELL_TYPE: d = k_synth_shells; n = 4; break;
+    case HIPCOL_TIMESTAMP: d = k_synth_time; n = 1; break;
+    case HIPCOL_WORKING_DIRECTORY: d = k_synth_dir; n = 1; break;
+    case HIPCOL_USER_NAME: d = k_synth_users; n = PQPS_SYNTH_USERS; break;
+    case HIPCOL_HOST_NAME: d = k_synth_hosts; n = 16; break;
+    default: break;
+    }
+    if (count) *count = n;
+    return d;
+}
+
+bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed) {
+    struct hipColumnData columns[HIPCOL_COUNT];
+    memset(columns, 0, sizeof columns);
+    static const char dummy = 0;                                     /* "values will be generated": not NULL */
+    for (int c = 0; c < HIPCOL_COUNT; c++) {
+        if (k_kind[c] != HIPKIND_DICT) { columns[c].width = k_numeric_width[c]; columns[c].values = &dummy; continue; }
+        columns[c].dictionary = hipSyntheticDictionary(c, &columns[c].dictionary_count);
+        if (columns[c].dictionary_count > 1) { columns[c].width = columns[c].dictionary_count > 256 ? 2 : 1; columns[c].values = &dummy; }
+    }
+    pqps_ctx **ctxs = NULL;
+    int n_shards = 0;
+    struct hipTable *t = columns_table(num_rows, columns, &ctxs, &n_shards);
+    uint32_t *cdf = malloc(PQPS_SYNTH_USERS * sizeof *cdf);
+    uint8_t *shell = malloc(PQPS_SYNTH_USERS);
+    if (!cdf || !shell) { perror("Failed to allocate memory for the synthetic table"); exit(EXIT_FAILURE); }
+    pqps_synth_user_tables(seed, cdf, shell);
+    for (int s = 0; s < n_shards; s++) {
+        struct hipTable *sh = hipTableShard(t, s);
+        void *cdf_dev = NULL, *shell_dev = NULL;
+        if (pqps_malloc(sh->ctx, PQPS_SYNTH_USERS * sizeof *cdf, &cdf_dev) != PQPS_OK || pqps_malloc(sh->ctx, PQPS_SYNTH_USERS, &shell_dev) != PQPS_OK ||
+            pqps_upload(sh->ctx, cdf_dev, cdf, PQPS_SYNTH_USERS * sizeof *cdf, NULL) != PQPS_OK || pqps_upload(sh->ctx, shell_dev, shell, PQPS_SYNTH_USERS, NULL) != PQPS_OK)
+            hip_die("synthetic table set-up");
+        pqps_synth_cols out;
+        memset(&out, 0, sizeof out);
+        out.command_id = (uint64_t *)sh->col[HIPCOL_COMMAND_ID].data;
+        out.exit_code = (int32_t *)sh->col[HIPCOL_EXIT_CODE].data;
+        out.user_id = (int32_t *)sh->col[HIPCOL_USER_ID].data;
+        out.risk_level = (int32_t *)sh->col[HIPCOL_RISK_LEVEL].data;
+        out.sudo_used = (uint8_t *)sh->col[HIPCOL_SUDO_USED].data;
+        out.shell_code = (uint8_t *)sh->col[HIPCOL_SHELL_TYPE].data;
+        out.user_code = (uint16_t *)sh->col[HIPCOL_USER_NAME].data;
+        out.host_code = (uint8_t *)sh->col[HIPCOL_HOST_NAME].data;
+        out.base_code = (uint8_t *)sh->col[HIPCOL_BASE_COMMAND].data;
+        if (sh->n_rows && pqps_synth_generate(sh->ctx, seed, sh->row0, sh->n_rows, cdf_dev, shell_dev, &out, NULL) != PQPS_OK) hip_die("synthetic table generation");
+        if (pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) hip_die("synthetic table generation");
+        pqps_free(sh->ctx, cdf_dev);
+        pqps_free(sh->ctx, shell_dev);
+    }
+    free(cdf); free(shell); free(ctxs);
+    table_make_engine(t);
+    engine->record_block = t;
+    return true;
 }

@@ -83,39 +83,6 @@ static void pass_columns(const struct hipTable *sh, const struct hipPass *pass, 
     }
 }
 
-/* Enqueues the passes before the last on the shard's stream (each one byte of flags per row) and binds the last. */
-static int shard_pred_prepare(struct hipTable *sh, const struct hipPlan *plan, struct shard_pred *sp) {
-    memset(sp, 0, sizeof *sp);
-    const struct hipPass *last = &plan->pass[plan->n_passes - 1];
-    if (plan->n_passes > 1) {
-        sp->flags = calloc((size_t)plan->n_passes - 1, sizeof *sp->flags);
-        if (!sp->flags) { fprintf(stderr, "HIP engine: out of memory\n"); return -1; }
-        sp->n_flags = plan->n_passes - 1;
-        for (int k = 0; k < sp->n_flags; k++) {
-            pqps_column cols[PQPS_MAX_COLUMNS];
-            TRY(pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&sp->flags[k]), "flag allocation");
-            pass_columns(sh, &plan->pass[k], sp->flags, cols);
-            TRY(pqps_filter_flags(sh->ctx, cols, plan->pass[k].pred.n_columns, sh->n_rows, &plan->pass[k].pred,
-                                  sp->flags[k], sh->count_dev + 4, NULL), "flag filter");
-        }
-    }
-    sp->pred = &last->pred;
-    sp->n_cols = last->pred.n_columns;
-    pass_columns(sh, last, sp->flags, sp->cols);
-    return 0;
-}
-
-static int ensure_id_capacity(struct hipTable *t, uint64_t need) {
-    if (need <= t->capacity_ids) return 0;
-    pqps_free(t->ctx, t->ids_dev);
-    t->ids_dev = NULL;
-    t->capacity_ids = 0;
-    const uint64_t cap = need + need / 8 + 1024;
-    TRY(pqps_malloc(t->ctx, cap * sizeof(uint32_t), (void **)&t->ids_dev), "result allocation");
-    t->capacity_ids = cap;
-    return 0;
-}
-
 /* Inclusive key window of an indexed top-level condition, S:377-424.
  * v + 1 / v - 1 wrap the way the reference's machine arithmetic does. */
 static void key_window_u64(const char *op, const char *value, uint64_t *lo, uint64_t *hi) {
@@ -173,198 +140,396 @@ static int list_probes(struct engineS *engine, const struct hipTable *t, struct 
     return n;
 }
 
-/* Result of one row selection.  Scan mode: shard s holds count[s] ascending engine row numbers in its ids_dev;
- * the answer is their concatenation in shard order.  Index mode: per probe, each shard appended its rows in
- * (key asc, row desc) order; on one shard that is the answer as it stands, on several `merged` holds it. */
-struct selection {
+/* ---- one query on the device(s) -------------------------------------------------------------------------
+ * Row selection of executeQuerySelectSerial, S:358-474.  A query is ISSUED -- everything it needs is enqueued on
+ * every shard, nothing is waited for -- and later AWAITED.  Engine tables give it a lane: result buffers of its own
+ * on every shard and a slot of the shards' query streams (so several queries are on the device at once); a table
+ * without lanes (ad-hoc tables over caller-supplied rows) runs it on the table's own context and buffers.
+ *
+ * Result.  Scan mode: shard s holds count[s] ascending engine row numbers; the answer is their concatenation in
+ * shard order.  Index mode: per probe, each shard appended its rows in (key asc, row desc) order; several shards
+ * are merged by key on shard 0's device.  `ids_dev` = the whole answer on shard 0's device (one shard: its lane's
+ * buffer as it stands; several: the gathered list). */
+struct query {
+    struct engineS *engine;
+    struct hipTable *t;
+    int lane;                            /* -1: the table's own buffers */
+    int n_shards;
+    bool count_only;
+    struct hipPlan plan;
+    bool have_plan;
+    struct probe *probes;
+    int n_probes;
+    struct shard_pred sp[HIP_MAX_SHARDS];
+    uint64_t *seg_dev[HIP_MAX_SHARDS];   /* index mode, several shards: running count after each probe */
+    /* after await */
     uint64_t total;
     uint64_t count[HIP_MAX_SHARDS];
-    unsigned int *merged;            /* host, `total` entries; index mode over several shards only */
+    const uint32_t *ids_dev;
+    pqps_ctx *ids_ctx;                   /* a context of the device ids_dev lives on (downloads) */
 };
 
-static uint64_t row_key(const record *r, const FieldInfo *fi) {
-    const char *p = (const char *)r + fi->offset;
-    return fi->type == FIELD_UINT64 ? *(const uint64_t *)p : (uint64_t)((int64_t)*(const int *)p + 0x80000000ll);
+static struct hipLane *query_lane(const struct query *q, int s) {
+    struct hipTable *sh = hipTableShard(q->t, s);
+    return q->lane >= 0 ? &sh->lane[q->lane] : &sh->own;
 }
 
-/* Row selection of executeQuerySelectSerial, S:358-474, on the device(s). */
-static int run_selection(struct engineS *engine, struct hipTable *t, struct whereClauseS *where, struct selection *sel) {
-    memset(sel, 0, sizeof *sel);
-    const int n_shards = hipTableShards(t);
-    struct hipPlan plan;
-    if (bind_where(t, where, &plan) != 0) return -1;
-    struct probe *probes = NULL;
-    const int n_probes = list_probes(engine, t, where, &probes);
-    struct shard_pred sp[HIP_MAX_SHARDS];
-    memset(sp, 0, sizeof sp);
-    uint64_t *seg_end = NULL;                                          /* [probe][shard] running counts */
-    int rc = n_probes < 0 ? -1 : 0;
-#define RUN(call, what) do { if (rc == 0 && (call) != PQPS_OK) rc = engine_error(what); } while (0)
-    for (int s = 0; s < n_shards && rc == 0; s++) rc = shard_pred_prepare(hipTableShard(t, s), &plan, &sp[s]);
-    if (rc == 0 && n_probes > 0 && n_shards > 1) {
-        seg_end = malloc((size_t)n_probes * (size_t)n_shards * sizeof *seg_end);
-        if (!seg_end) rc = -1;
+/* context for the lane's own copies / gathers (never the stream the scans run on) */
+static pqps_ctx *lane_copy_ctx(const struct query *q, int s) {
+    struct hipLane *L = query_lane(q, s);
+    return L->copy ? L->copy : hipTableShard(q->t, s)->ctx;
+}
+
+static void query_init(struct query *q, struct engineS *engine, struct hipTable *t, int lane, bool count_only) {
+    memset(q, 0, sizeof *q);
+    q->engine = engine;
+    q->t = t;
+    q->lane = lane;
+    q->n_shards = hipTableShards(t);
+    q->count_only = count_only;
+}
+
+static void query_free(struct query *q) {
+    for (int s = 0; s < q->n_shards; s++) {
+        struct hipTable *sh = hipTableShard(q->t, s);
+        shard_pred_free(sh, &q->sp[s]);
+        if (q->seg_dev[s]) { pqps_free(sh->ctx, q->seg_dev[s]); q->seg_dev[s] = NULL; }
     }
-    for (bool again = true; rc == 0 && again; ) {
-        again = false;
-        if (n_probes > 0) {
-            for (int s = 0; s < n_shards; s++) {
-                struct hipTable *sh = hipTableShard(t, s);
-                RUN(pqps_memset(sh->ctx, sh->count_dev, 0, sizeof(uint64_t), NULL), "counter reset");
-            }
-            for (int k = 0; k < n_probes && rc == 0; k++) {
-                for (int s = 0; s < n_shards; s++) {
-                    struct hipTable *sh = hipTableShard(t, s);
-                    const struct hipIndex *ix = &sh->index[probes[k].index];
-                    uint64_t *range_dev = sh->count_dev + 2;
-                    RUN(pqps_index_probe(sh->ctx, ix->keys_dev, sh->col[ix->column].width, ix->key_kind,
-                                         sh->n_rows, probes[k].lo, probes[k].hi, range_dev, NULL), "index probe");
-                    /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
-                    RUN(pqps_filter_gather(sh->ctx, sp[s].cols, sp[s].n_cols, ix->perm_dev, range_dev, sh->n_rows,
-                                           (uint32_t)sh->row0, sp[s].pred, sh->ids_dev, sh->capacity_ids, sh->count_dev, NULL), "index filter");
-                }
-                if (seg_end)                                           /* where this probe's rows end on every shard */
-                    for (int s = 0; s < n_shards; s++) {
-                        struct hipTable *sh = hipTableShard(t, s);
-                        RUN(pqps_download(sh->ctx, &seg_end[(size_t)k * (size_t)n_shards + (size_t)s], sh->count_dev, sizeof(uint64_t), NULL), "count download");
-                    }
-            }
-        } else {                                                       /* full scan, S:464-467: all shards at once */
-            for (int s = 0; s < n_shards; s++) {
-                struct hipTable *sh = hipTableShard(t, s);
-                RUN(pqps_filter_scan(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, (uint32_t)sh->row0, sp[s].pred,
-                                     sh->ids_dev, sh->capacity_ids, sh->count_dev, NULL), "scan filter");
-            }
-        }
-        sel->total = 0;
-        for (int s = 0; s < n_shards; s++) {
-            struct hipTable *sh = hipTableShard(t, s);
-            RUN(pqps_ctx_sync(sh->ctx, NULL), "filter execution");
-            RUN(pqps_download(sh->ctx, &sel->count[s], sh->count_dev, sizeof(uint64_t), NULL), "count download");
-            if (rc == 0 && sel->count[s] > sh->capacity_ids) {         /* duplicates can exceed n rows: retry larger */
-                rc = ensure_id_capacity(sh, sel->count[s]);
-                again = true;
-            }
-            sel->total += sel->count[s];
+    free(q->probes);
+    q->probes = NULL;
+    if (q->have_plan) { hipPlanFree(&q->plan); q->have_plan = false; }
+}
+
+/* The filter calls of the query on shard s, on (ctx, stream): flag passes, then the count, the probes + gather
+ * filters, or the scan. */
+static int issue_calls(struct query *q, int s, pqps_ctx *ctx, void *stream) {
+    struct hipTable *sh = hipTableShard(q->t, s);
+    struct hipLane *L = query_lane(q, s);
+    struct shard_pred *sp = &q->sp[s];
+    const struct hipPlan *plan = &q->plan;
+    const struct hipPass *last = &plan->pass[plan->n_passes - 1];
+    /* the passes before the last: one byte of flags per row each */
+    if (plan->n_passes > 1) {
+        sp->flags = calloc((size_t)plan->n_passes - 1, sizeof *sp->flags);
+        if (!sp->flags) { fprintf(stderr, "HIP engine: out of memory\n"); return -1; }
+        sp->n_flags = plan->n_passes - 1;
+        for (int k = 0; k < sp->n_flags; k++) {
+            pqps_column cols[PQPS_MAX_COLUMNS];
+            TRY(pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&sp->flags[k]), "flag allocation");
+            pass_columns(sh, &plan->pass[k], sp->flags, cols);
+            TRY(pqps_filter_flags(ctx, cols, plan->pass[k].pred.n_columns, sh->n_rows, &plan->pass[k].pred,
+                                  sp->flags[k], L->count_dev + 4, stream), "flag filter");
         }
     }
-    if (rc == 0 && seg_end && sel->total > 0) {
-        /* several shards, index mode: every probe's segment is sorted by (key asc, row desc) on each shard, and
-         * the shards hold ascending row ranges -- merge the segments probe by probe */
-        unsigned int *part[HIP_MAX_SHARDS];
-        memset(part, 0, sizeof part);
-        sel->merged = malloc(sel->total * sizeof *sel->merged);
-        if (!sel->merged) rc = -1;
-        for (int s = 0; s < n_shards && rc == 0; s++) {
-            struct hipTable *sh = hipTableShard(t, s);
-            part[s] = malloc((sel->count[s] ? sel->count[s] : 1) * sizeof **part);
-            if (!part[s]) { rc = -1; break; }
-            if (sel->count[s]) RUN(pqps_download(sh->ctx, part[s], sh->ids_dev, sel->count[s] * sizeof **part, NULL), "ID download");
+    sp->pred = &last->pred;
+    sp->n_cols = last->pred.n_columns;
+    pass_columns(sh, last, sp->flags, sp->cols);
+    if (q->count_only) {
+        TRY(pqps_filter_count(ctx, sp->cols, sp->n_cols, sh->n_rows, sp->pred, L->count_dev, stream), "count filter");
+    } else if (q->n_probes > 0) {
+        TRY(pqps_memset(ctx, L->count_dev, 0, sizeof(uint64_t), stream), "counter reset");
+        if (q->n_shards > 1 && !q->seg_dev[s]) TRY(pqps_malloc(sh->ctx, (size_t)q->n_probes * sizeof(uint64_t), (void **)&q->seg_dev[s]), "segment counters");
+        for (int k = 0; k < q->n_probes; k++) {
+            const struct hipIndex *ix = &sh->index[q->probes[k].index];
+            uint64_t *range_dev = L->count_dev + 2;
+            TRY(pqps_index_probe(ctx, ix->keys_dev, sh->col[ix->column].width, ix->key_kind, sh->n_rows, q->probes[k].lo, q->probes[k].hi,
+                                 range_dev, stream), "index probe");
+            /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
+            TRY(pqps_filter_gather(ctx, sp->cols, sp->n_cols, ix->perm_dev, range_dev, sh->n_rows, (uint32_t)sh->row0, sp->pred,
+                                   L->ids_dev, L->capacity_ids, L->count_dev, stream), "index filter");
+            if (q->seg_dev[s])                                     /* where this probe's rows end on this shard */
+                TRY(pqps_copy_peer(ctx, q->seg_dev[s] + k, ctx, L->count_dev, sizeof(uint64_t), stream), "segment counter");
         }
-        uint64_t w = 0, at[HIP_MAX_SHARDS];
-        memset(at, 0, sizeof at);
-        for (int k = 0; k < n_probes && rc == 0; k++) {
-            const FieldInfo *fi = get_field_info(engine->indexed_attributes[probes[k].index]);
-            const uint64_t *end = &seg_end[(size_t)k * (size_t)n_shards];
-            for (;;) {
-                int best = -1;
-                uint64_t best_key = 0;
-                for (int s = n_shards - 1; s >= 0; s--) {             /* ties: the higher rows (later shard) first */
-                    if (at[s] >= end[s]) continue;
-                    const uint64_t key = row_key(engine->all_records[part[s][at[s]]], fi);
-                    if (best < 0 || key < best_key) { best = s; best_key = key; }
-                }
-                if (best < 0) break;
-                sel->merged[w++] = part[best][at[best]++];
-            }
-        }
-        for (int s = 0; s < n_shards; s++) free(part[s]);
+    } else {
+        TRY(pqps_filter_scan(ctx, sp->cols, sp->n_cols, sh->n_rows, (uint32_t)sh->row0, sp->pred, L->ids_dev, L->capacity_ids,
+                             L->count_dev, stream), "scan filter");
     }
-#undef RUN
-    for (int s = 0; s < n_shards; s++) shard_pred_free(hipTableShard(t, s), &sp[s]);
-    free(seg_end);
-    free(probes);
-    hipPlanFree(&plan);
-    if (rc != 0) { free(sel->merged); sel->merged = NULL; }
+    return 0;
+}
+
+/* Everything of the query that runs on shard s.  A single-pass scan or count on a lane is ONE call into the shard's
+ * query stream, whose completion event rides on the launch itself. */
+static int issue_on_shard(struct query *q, int s) {
+    struct hipTable *sh = hipTableShard(q->t, s);
+    struct hipLane *L = query_lane(q, s);
+    struct shard_pred *sp = &q->sp[s];
+    memset(sp, 0, sizeof *sp);
+    const struct hipPlan *plan = &q->plan;
+    const struct hipPass *last = &plan->pass[plan->n_passes - 1];
+    const bool single = plan->n_passes == 1 && q->n_probes == 0;
+    if (q->lane >= 0 && single) {
+        sp->pred = &last->pred;
+        sp->n_cols = last->pred.n_columns;
+        pass_columns(sh, last, NULL, sp->cols);
+        if (q->count_only)
+            TRY(pqps_qstream_count_slot(sh->qs, (uint32_t)q->lane, sp->cols, sp->n_cols, sh->n_rows, sp->pred, L->count_dev, NULL), "count filter");
+        else
+            TRY(pqps_qstream_scan_slot(sh->qs, (uint32_t)q->lane, sp->cols, sp->n_cols, sh->n_rows, (uint32_t)sh->row0, sp->pred,
+                                       L->ids_dev, L->capacity_ids, L->count_dev, NULL), "scan filter");
+        return 0;
+    }
+    pqps_ctx *ctx = sh->ctx;
+    void *stream = NULL;
+    if (q->lane >= 0) TRY(pqps_qstream_lane(sh->qs, (uint32_t)q->lane, sh->n_rows, NULL, &ctx, &stream), "query lane");
+    const int rc = issue_calls(q, s, ctx, stream);
+    /* the end of whatever reached the lane's stream is marked even if a call failed half-way: the lane's buffers must
+     * not be handed to another query while a launch of this one still runs */
+    if (q->lane >= 0 && pqps_qstream_mark(sh->qs, (uint32_t)q->lane) != PQPS_OK && rc == 0) return engine_error("query lane");
     return rc;
 }
 
-/* Caller holds the rows lock (shared).  The device phase -- the contexts' scratch and the shards'
- * result buffers serve one query at a time -- runs under the device lock. */
-static long long select_ids(struct engineS *engine, struct whereClauseS *whereClause,
-                            unsigned int **ids, double *queryTime) {
-    struct hipTable *t = engine->record_block;
-    const double t0 = now_seconds();
-    struct selection sel;
-    *ids = NULL;
-    hipTableLockDevice(t);
-    int rc = run_selection(engine, t, whereClause, &sel);
-    unsigned int *out = NULL;
-    if (rc == 0 && sel.merged) {
-        out = sel.merged;
-    } else if (rc == 0) {
-        out = malloc((sel.total ? sel.total : 1) * sizeof *out);
-        if (!out) { fprintf(stderr, "HIP engine: out of memory for %llu result IDs\n", (unsigned long long)sel.total); rc = -1; }
-        uint64_t at = 0;
-        for (int s = 0; s < hipTableShards(t) && rc == 0; s++) {
-            struct hipTable *sh = hipTableShard(t, s);
-            if (sel.count[s] && pqps_download(sh->ctx, out + at, sh->ids_dev, sel.count[s] * sizeof *out, NULL) != PQPS_OK)
-                rc = engine_error("ID download");
-            at += sel.count[s];
-        }
-        if (rc != 0) { free(out); out = NULL; }
+static int query_issue_all(struct query *q) {
+    int rc = 0;
+    hipTableLockIssue(q->t);
+    for (int s = 0; s < q->n_shards && rc == 0; s++) {
+        shard_pred_free(hipTableShard(q->t, s), &q->sp[s]);            /* (a re-issue after a result buffer had to grow) */
+        rc = issue_on_shard(q, s);
     }
-    hipTableUnlockDevice(t);
-    if (queryTime) *queryTime = now_seconds() - t0;
-    *ids = out;
-    return rc == 0 ? (long long)sel.total : -1;
+    hipTableUnlockIssue(q->t);
+    return rc;
 }
 
-long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
-                                   unsigned int **ids, double *queryTime) {
-    if (!engine || !engine->record_block || !ids) return -1;
-    hipTableLockShared(engine->record_block);
-    const long long count = select_ids(engine, whereClause, ids, queryTime);
-    hipTableUnlock(engine->record_block);
+/* Compiles the WHERE, lists the probes, enqueues the query on every shard. */
+static int query_issue(struct query *q, struct whereClauseS *where) {
+    if (bind_where(q->t, where, &q->plan) != 0) return -1;
+    q->have_plan = true;
+    if (!q->count_only) {
+        q->n_probes = list_probes(q->engine, q->t, where, &q->probes);     /* COUNT(*) is the scan-mode count */
+        if (q->n_probes < 0) { q->n_probes = 0; return -1; }
+    }
+    return query_issue_all(q);
+}
+
+static int wait_shard(struct query *q, int s) {
+    struct hipTable *sh = hipTableShard(q->t, s);
+    if (q->lane >= 0) TRY(pqps_qstream_wait(sh->qs, (uint32_t)q->lane), "filter execution");
+    else TRY(pqps_ctx_sync(sh->ctx, NULL), "filter execution");
+    return 0;
+}
+
+static int grow_lane_ids(struct hipTable *sh, struct hipLane *L, uint64_t need) {
+    if (need <= L->capacity_ids) return 0;
+    pqps_free(sh->ctx, L->ids_dev);
+    L->ids_dev = NULL;
+    L->capacity_ids = 0;
+    const uint64_t cap = need + need / 8 + 1024;
+    TRY(pqps_malloc(sh->ctx, cap * sizeof(uint32_t), (void **)&L->ids_dev), "result allocation");
+    L->capacity_ids = cap;
+    return 0;
+}
+
+/* Several shards: the answer in one piece on shard 0's device.  Scan mode = the concatenation of the shards' lists in
+ * shard order, placed by peer copies at the displacements the counts give (MPI_Allgather of the sizes, exclusive prefix,
+ * MPI_Allgatherv: mpi:753-765).  Index mode = per probe the union of the shards' segments sorted by (key asc, row
+ * desc) -- every segment is in that order already and a later shard holds later rows, so this is the table-wide
+ * leaf order of the reference's tree: keys gathered on each shard, segments and keys copied over, merged by the
+ * device sort behind pqps_merge_index_slots. */
+static int gather_shards(struct query *q) {
+    struct hipTable *t = q->t;
+    struct hipLane *L0 = query_lane(q, 0);
+    pqps_ctx *c0 = lane_copy_ctx(q, 0);
+    if (q->total > L0->merged_cap) {
+        if (L0->merged_dev) pqps_free(t->ctx, L0->merged_dev);
+        L0->merged_dev = NULL;
+        L0->merged_cap = 0;
+        const uint64_t cap = q->total + q->total / 8 + 1024;
+        TRY(pqps_malloc(t->ctx, cap * sizeof(uint32_t), (void **)&L0->merged_dev), "gathered list allocation");
+        L0->merged_cap = cap;
+    }
+    q->ids_dev = L0->merged_dev;
+    q->ids_ctx = c0;
+    if (q->total == 0) return 0;
+    if (q->n_probes == 0) {
+        uint64_t at = 0;
+        for (int s = 0; s < q->n_shards; s++) {
+            TRY(pqps_copy_peer(c0, L0->merged_dev + at, lane_copy_ctx(q, s), query_lane(q, s)->ids_dev, q->count[s] * sizeof(uint32_t), NULL), "peer copy");
+            at += q->count[s];
+        }
+        TRY(pqps_ctx_sync(c0, NULL), "peer copy");
+        return 0;
+    }
+    /* index mode */
+    uint64_t *ends = malloc((size_t)q->n_probes * (size_t)q->n_shards * sizeof *ends);       /* [shard][probe] */
+    if (!ends) return -1;
+    int rc = 0;
+#define RUN(call, what) do { if (rc == 0 && (call) != PQPS_OK) rc = engine_error(what); } while (0)
+    for (int s = 0; s < q->n_shards; s++)
+        RUN(pqps_download(lane_copy_ctx(q, s), ends + (size_t)s * (size_t)q->n_probes, q->seg_dev[s], (size_t)q->n_probes * sizeof *ends, NULL), "segment counters");
+    uint64_t out_at = 0;
+    for (int k = 0; k < q->n_probes && rc == 0; k++) {
+        uint64_t seg_total = 0, seg_len[HIP_MAX_SHARDS], seg_begin[HIP_MAX_SHARDS];
+        for (int s = 0; s < q->n_shards; s++) {
+            const uint64_t *e = ends + (size_t)s * (size_t)q->n_probes;
+            seg_begin[s] = k ? e[k - 1] : 0;
+            seg_len[s] = e[k] - seg_begin[s];
+            seg_total += seg_len[s];
+        }
+        if (seg_total == 0) continue;
+        const uint64_t stride = ((seg_total + 1) & ~1ull) + PQPS_SLOT_HEADER_WORDS;
+        uint32_t *slots = NULL;
+        uint64_t *keys = NULL, *totals_dev = NULL;
+        RUN(pqps_malloc(t->ctx, stride * sizeof(uint32_t), (void **)&slots), "merge buffer");
+        RUN(pqps_malloc(t->ctx, (stride - PQPS_SLOT_HEADER_WORDS) * sizeof(uint64_t), (void **)&keys), "merge buffer");
+        RUN(pqps_malloc(t->ctx, 2 * sizeof(uint64_t), (void **)&totals_dev), "merge buffer");
+        const uint64_t header[2] = { seg_total, 0 };
+        RUN(pqps_upload(c0, slots, header, sizeof header, NULL), "merge header");
+        uint64_t at = 0;
+        for (int s = 0; s < q->n_shards && rc == 0; s++) {
+            if (seg_len[s] == 0) continue;
+            struct hipTable *sh = hipTableShard(t, s);
+            struct hipLane *L = query_lane(q, s);
+            pqps_ctx *cs = lane_copy_ctx(q, s);
+            const struct hipIndex *ix = &sh->index[q->probes[k].index];
+            uint64_t *keys_s = NULL;
+            RUN(pqps_malloc(sh->ctx, seg_len[s] * sizeof(uint64_t), (void **)&keys_s), "key buffer");
+            /* (the count word on the device is the shard's total >= the segment's length: the capacity argument bounds the gather) */
+            RUN(pqps_gather_keys(cs, &sh->col[ix->column], ix->key_kind, L->ids_dev + seg_begin[s], L->count_dev, seg_len[s], (uint32_t)sh->row0, keys_s, NULL), "key gather");
+            RUN(pqps_ctx_sync(cs, NULL), "key gather");
+            RUN(pqps_copy_peer(c0, slots + PQPS_SLOT_HEADER_WORDS + at, cs, L->ids_dev + seg_begin[s], seg_len[s] * sizeof(uint32_t), NULL), "peer copy");
+            RUN(pqps_copy_peer(c0, keys + at, cs, keys_s, seg_len[s] * sizeof(uint64_t), NULL), "peer copy");
+            RUN(pqps_ctx_sync(c0, NULL), "peer copy");
+            if (keys_s) pqps_free(sh->ctx, keys_s);
+            at += seg_len[s];
+        }
+        RUN(pqps_merge_index_slots(c0, slots, keys, 1, stride, L0->merged_dev + out_at, L0->merged_cap - out_at, totals_dev, NULL), "index merge");
+        out_at += seg_total;
+        if (slots) pqps_free(t->ctx, slots);
+        if (keys) pqps_free(t->ctx, keys);
+        if (totals_dev) pqps_free(t->ctx, totals_dev);
+    }
+#undef RUN
+    free(ends);
+    return rc;
+}
+
+/* Waits for the query; a result buffer that turned out too small (index-mode duplicates can exceed the table's rows)
+ * is grown and the query issued again. */
+static int query_await(struct query *q) {
+    for (;;) {
+        bool again = false;
+        int rc = 0;
+        q->total = 0;
+        for (int s = 0; s < q->n_shards; s++) {
+            struct hipTable *sh = hipTableShard(q->t, s);
+            struct hipLane *L = query_lane(q, s);
+            if (rc == 0) rc = wait_shard(q, s);
+            if (rc == 0 && pqps_download(lane_copy_ctx(q, s), &q->count[s], L->count_dev, sizeof(uint64_t), NULL) != PQPS_OK) rc = engine_error("count download");
+            if (rc == 0 && !q->count_only && q->count[s] > L->capacity_ids) {
+                rc = grow_lane_ids(sh, L, q->count[s]);
+                again = true;
+            }
+            q->total += q->count[s];
+        }
+        if (rc != 0) return rc;
+        if (!again) break;
+        if (query_issue_all(q) != 0) return -1;
+    }
+    if (q->count_only) return 0;
+    if (q->n_shards == 1) {
+        q->ids_dev = query_lane(q, 0)->ids_dev;
+        q->ids_ctx = lane_copy_ctx(q, 0);
+        return 0;
+    }
+    return gather_shards(q);
+}
+
+/* ---- asynchronous tickets (include/executeEngine-hip.h) ------------------------------------------------ */
+
+struct hipQueryTicket {
+    struct query q;
+    double t0;
+    int state;                       /* 0 issued, 1 awaited, -1 failed */
+};
+
+static struct hipQueryTicket *ticket_begin(struct engineS *engine, struct whereClauseS *where, bool count_only) {
+    if (!engine || !engine->record_block) return NULL;
+    struct hipTable *t = engine->record_block;
+    struct hipQueryTicket *tk = calloc(1, sizeof *tk);
+    if (!tk) { fprintf(stderr, "HIP engine: out of memory\n"); return NULL; }
+    tk->t0 = now_seconds();
+    hipTableLockShared(t);                                            /* until releaseQueryHIP: no writer meanwhile */
+    query_init(&tk->q, engine, t, hipTableAcquireLane(t), count_only);
+    if (query_issue(&tk->q, where) != 0) tk->state = -1;            /* reason on stderr; awaitQueryHIP reports -1 */
+    return tk;
+}
+
+struct hipQueryTicket *executeQuerySelectAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause) {
+    return ticket_begin(engine, whereClause, false);
+}
+
+struct hipQueryTicket *executeQueryCountAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause) {
+    return ticket_begin(engine, whereClause, true);
+}
+
+long long awaitQueryHIP(struct hipQueryTicket *tk, struct hipDeviceResult *result) {
+    if (result) memset(result, 0, sizeof *result);
+    if (!tk) return -1;
+    if (tk->state == 0) tk->state = query_await(&tk->q) == 0 ? 1 : -1;
+    if (tk->state < 0) { if (result) result->count = -1; return -1; }
+    if (result) {
+        result->count = (long long)tk->q.total;
+        result->ids_dev = tk->q.count_only ? NULL : tk->q.ids_dev;
+        result->device = pqps_ctx_device(tk->q.t->ctx);
+        result->n_shards = tk->q.n_shards;
+        for (int s = 0; s < tk->q.n_shards && s < 16; s++) result->shard_count[s] = tk->q.count[s];
+    }
+    return (long long)tk->q.total;
+}
+
+/* The lane goes back (its device buffers are no longer this query's); the table stays locked shared. */
+static void ticket_release_lane(struct hipQueryTicket *tk) {
+    if (tk->state == 2) return;
+    /* never leave a launch behind that writes into a freed lane */
+    if (tk->state == 0) (void)query_await(&tk->q);
+    else if (tk->state < 0) for (int sx = 0; sx < tk->q.n_shards; sx++) (void)wait_shard(&tk->q, sx);
+    query_free(&tk->q);
+    hipTableReleaseLane(tk->q.t, tk->q.lane);
+    tk->state = 2;
+}
+
+void releaseQueryHIP(struct hipQueryTicket *tk) {
+    if (!tk) return;
+    struct hipTable *t = tk->q.t;
+    ticket_release_lane(tk);
+    hipTableUnlockShared(t);
+    free(tk);
+}
+
+/* The answer's row numbers on the host (malloc'd); -1 on error. */
+static long long ticket_download_ids(struct hipQueryTicket *tk, unsigned int **ids) {
+    *ids = NULL;
+    long long count = awaitQueryHIP(tk, NULL);
+    if (count < 0) return -1;
+    unsigned int *out = malloc((count ? (size_t)count : 1) * sizeof *out);
+    if (!out) { fprintf(stderr, "HIP engine: out of memory for %lld result IDs\n", count); return -1; }
+    if (count && pqps_download(tk->q.ids_ctx, out, tk->q.ids_dev, (size_t)count * sizeof *out, NULL) != PQPS_OK) {
+        engine_error("ID download");
+        free(out);
+        return -1;
+    }
+    *ids = out;
     return count;
 }
 
-static int count_rows(struct hipTable *t, struct whereClauseS *whereClause, uint64_t *total) {
-    struct hipPlan plan;
-    if (bind_where(t, whereClause, &plan) != 0) return -1;
-    const int n_shards = hipTableShards(t);
-    struct shard_pred sp[HIP_MAX_SHARDS];
-    memset(sp, 0, sizeof sp);
-    int rc = 0;
-    *total = 0;
-    for (int s = 0; s < n_shards && rc == 0; s++) {
-        struct hipTable *sh = hipTableShard(t, s);
-        rc = shard_pred_prepare(sh, &plan, &sp[s]);
-        if (rc == 0 && pqps_filter_count(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, sp[s].pred, sh->count_dev, NULL) != PQPS_OK)
-            rc = engine_error("count filter");
-    }
-    for (int s = 0; s < n_shards; s++) {
-        struct hipTable *sh = hipTableShard(t, s);
-        uint64_t count = 0;
-        if (rc == 0 && pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) rc = engine_error("filter execution");
-        if (rc == 0 && pqps_download(sh->ctx, &count, sh->count_dev, sizeof count, NULL) != PQPS_OK) rc = engine_error("count download");
-        *total += count;
-        shard_pred_free(sh, &sp[s]);
-    }
-    hipPlanFree(&plan);
-    return rc;
+/* The filter without the projection: the row numbers on the host. */
+long long executeQuerySelectIdsHIP(struct engineS *engine, struct whereClauseS *whereClause,
+                                   unsigned int **ids, double *queryTime) {
+    if (!engine || !engine->record_block || !ids) return -1;
+    *ids = NULL;
+    const double t0 = now_seconds();
+    struct hipQueryTicket *tk = executeQuerySelectAsyncHIP(engine, whereClause);
+    const long long count = tk ? ticket_download_ids(tk, ids) : -1;
+    releaseQueryHIP(tk);
+    if (queryTime) *queryTime = now_seconds() - t0;
+    return count;
 }
 
 long long executeQueryCountHIP(struct engineS *engine, struct whereClauseS *whereClause) {
     if (!engine || !engine->record_block) return -1;
-    struct hipTable *t = engine->record_block;
-    uint64_t total = 0;
-    hipTableLockShared(t);
-    hipTableLockDevice(t);
-    const int rc = count_rows(t, whereClause, &total);
-    hipTableUnlockDevice(t);
-    hipTableUnlock(t);
-    return rc == 0 ? (long long)total : -1;
+    struct hipQueryTicket *tk = executeQueryCountAsyncHIP(engine, whereClause);
+    const long long count = awaitQueryHIP(tk, NULL);
+    releaseQueryHIP(tk);
+    return count;
 }
 
 /* ---- projection ------------------------------------------------------------------ */
@@ -406,9 +571,13 @@ static void *project_rows(void *arg) {
     return NULL;
 }
 
+static struct resultSetS *select_device_only(struct engineS *engine, const char **selectItems, int numSelectItems, struct whereClauseS *whereClause);
+
 struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **selectItems, int numSelectItems,
                                          const char *tableName, struct whereClauseS *whereClause) {
     (void)tableName;                                   /* never checked by the reference either */
+    if (engine && engine->record_block && ((struct hipTable *)engine->record_block)->device_only)
+        return select_device_only(engine, selectItems, numSelectItems, whereClause);
     struct resultSetS *rs = malloc(sizeof *rs);
     if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
     memset(rs, 0, sizeof *rs);
@@ -416,10 +585,13 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
     unsigned int *ids = NULL;
     double qtime = 0.0;
     if (!engine || !engine->record_block) { rs->success = false; return rs; }
-    hipTableLockShared(engine->record_block);          /* the projection below reads the host rows */
-    const long long count = select_ids(engine, whereClause, &ids, &qtime);
+    const double t_sel = now_seconds();
+    struct hipQueryTicket *tk = executeQuerySelectAsyncHIP(engine, whereClause);    /* holds the table shared: the projection below reads the host rows */
+    const long long count = tk ? ticket_download_ids(tk, &ids) : -1;
+    if (tk) ticket_release_lane(tk);                   /* the device side is done: the lane serves the next query while this one builds strings */
+    qtime = now_seconds() - t_sel;
     if (count < 0) {                                   /* reason already on stderr */
-        hipTableUnlock(engine->record_block);
+        releaseQueryHIP(tk);
         rs->success = false;
         return rs;
     }
@@ -455,7 +627,7 @@ struct resultSetS *executeQuerySelectHIP(struct engineS *engine, const char **se
         if (nt == 1 || pthread_create(&tid[k], NULL, project_rows, &job[k]) != 0) { project_rows(&job[k]); tid[k] = 0; }
     }
     for (int k = 0; k < nt; k++) if (nt > 1 && tid[k]) pthread_join(tid[k], NULL);
-    hipTableUnlock(engine->record_block);
+    releaseQueryHIP(tk);
     TRACE("SELECT: %lld rows x %d columns, selection %.3f ms, projection %.3f ms (%d threads)\n", count, rs->numColumns,
           qtime * 1e3, (now_seconds() - t_proj) * 1e3, nt);
     free(cols);
@@ -488,6 +660,13 @@ static int own_dictionary(struct hipColumnarResult *res, int j, const struct hip
     for (int v = 0; v < d->count; v++) {
         if (!local[v]) continue;
         values[k] = strdup(d->values[v]);
+        if (!values[k]) {                                               /* hand over what exists: freeColumnarResultHIP frees it */
+            free(local);
+            res->dictionaries[j] = (const char *const *)values;
+            res->dictionarySizes[j] = k;
+            fprintf(stderr, "HIP engine: out of memory for the result set\n");
+            return -1;
+        }
         local[v] = (uint32_t)k++;
     }
     for (uint64_t i = 0; i < count; i++) wide[i] = local[wide[i]];
@@ -497,20 +676,23 @@ static int own_dictionary(struct hipColumnarResult *res, int j, const struct hip
     return 0;
 }
 
-/* Device gather of one column for the selected rows of every shard, into `raw` (result order). */
-static int project_column(struct hipTable *t, const struct selection *sel, int c, void *const *gathered,
-                          unsigned int *const *sub_pos, char *raw, char *tmp) {
+/* Device gather of one column for the selected rows of every shard, into `raw` (result order).  `scattered`: the
+ * shards' rows are interleaved in the result (index mode over several shards): shard s's k-th row goes to sub_pos[s][k]. */
+static int project_column(struct query *q, int c, void *const *gathered, bool scattered, unsigned int *const *sub_pos, char *raw, char *tmp) {
+    struct hipTable *t = q->t;
     const uint32_t w = t->col[c].width;
     uint64_t at = 0;
-    for (int s = 0; s < hipTableShards(t); s++) {
+    for (int s = 0; s < q->n_shards; s++) {
         struct hipTable *sh = hipTableShard(t, s);
-        const uint64_t k = sel->count[s];
+        struct hipLane *L = query_lane(q, s);
+        pqps_ctx *cs = lane_copy_ctx(q, s);
+        const uint64_t k = q->count[s];
         if (k == 0) continue;
-        TRY(pqps_project_column(sh->ctx, &sh->col[c], sh->ids_dev, sh->count_dev, k, (uint32_t)sh->row0, gathered[s], NULL), "device projection");
-        if (!sel->merged) {
-            TRY(pqps_download(sh->ctx, raw + at * w, gathered[s], k * w, NULL), "projection download");
-        } else {                                                        /* rows of this shard are scattered over the merged order */
-            TRY(pqps_download(sh->ctx, tmp, gathered[s], k * w, NULL), "projection download");
+        TRY(pqps_project_column(cs, &sh->col[c], L->ids_dev, L->count_dev, k, (uint32_t)sh->row0, gathered[s], NULL), "device projection");
+        if (!scattered) {
+            TRY(pqps_download(cs, raw + at * w, gathered[s], k * w, NULL), "projection download");
+        } else {
+            TRY(pqps_download(cs, tmp, gathered[s], k * w, NULL), "projection download");
             for (uint64_t i = 0; i < k; i++) memcpy(raw + (size_t)sub_pos[s][i] * w, tmp + i * w, w);
         }
         at += k;
@@ -518,12 +700,16 @@ static int project_column(struct hipTable *t, const struct selection *sel, int c
     return 0;
 }
 
+/* Caller holds the table shared. */
 static int select_columnar(struct engineS *engine, struct hipTable *t, const char **selectItems, int numSelectItems,
                            struct whereClauseS *whereClause, struct hipColumnarResult *res) {
-    struct selection sel;
-    if (run_selection(engine, t, whereClause, &sel) != 0) return -1;    /* IDs stay in the shards' ids_dev, the counts in count_dev */
-    const int n_shards = hipTableShards(t);
-    const uint64_t count = sel.total;
+    struct query q;
+    query_init(&q, engine, t, hipTableAcquireLane(t), false);
+    int rc = query_issue(&q, whereClause);
+    if (rc == 0) rc = query_await(&q);
+    else for (int s = 0; s < q.n_shards; s++) (void)wait_shard(&q, s);
+    const int n_shards = q.n_shards;
+    const uint64_t count = rc == 0 ? q.total : 0;
     struct hipSchema schema;
     hipSchemaOfTable(t, &schema);
     void *gathered[HIP_MAX_SHARDS];
@@ -531,48 +717,56 @@ static int select_columnar(struct engineS *engine, struct hipTable *t, const cha
     memset(gathered, 0, sizeof gathered);
     memset(sub_pos, 0, sizeof sub_pos);
     char *tmp = NULL;
-    int rc = 0;
-    if (sel.merged) {
+    const bool scattered = rc == 0 && n_shards > 1 && q.n_probes > 0 && count > 0;
+    if (scattered) {
         /* index mode over several shards: each shard gathers for its own rows in merged order (its sub-list
-         * replaces the shard-order list on the device), the values are scattered to their merged positions */
+         * replaces the shard-order list in its lane), the values are scattered to their merged positions */
         uint64_t fill[HIP_MAX_SHARDS], biggest = 0;
         memset(fill, 0, sizeof fill);
         unsigned int *sub_ids[HIP_MAX_SHARDS];
         memset(sub_ids, 0, sizeof sub_ids);
+        unsigned int *merged = malloc(count * sizeof *merged);
+        if (!merged) rc = -1;
+        if (rc == 0 && pqps_download(q.ids_ctx, merged, q.ids_dev, count * sizeof *merged, NULL) != PQPS_OK) rc = engine_error("ID download");
         for (int s = 0; s < n_shards; s++) {
-            sub_ids[s] = malloc((sel.count[s] ? sel.count[s] : 1) * sizeof **sub_ids);
-            sub_pos[s] = malloc((sel.count[s] ? sel.count[s] : 1) * sizeof **sub_pos);
+            sub_ids[s] = malloc((q.count[s] ? q.count[s] : 1) * sizeof **sub_ids);
+            sub_pos[s] = malloc((q.count[s] ? q.count[s] : 1) * sizeof **sub_pos);
             if (!sub_ids[s] || !sub_pos[s]) rc = -1;
-            if (sel.count[s] > biggest) biggest = sel.count[s];
+            if (q.count[s] > biggest) biggest = q.count[s];
         }
         for (uint64_t i = 0; i < count && rc == 0; i++) {
-            const unsigned int id = sel.merged[i];
+            const unsigned int id = merged[i];
             int s = n_shards - 1;
             while (s > 0 && id < hipTableShard(t, s)->row0) s--;
             sub_ids[s][fill[s]] = id;
             sub_pos[s][fill[s]++] = (unsigned int)i;
         }
-        for (int s = 0; s < n_shards && rc == 0; s++) {
-            struct hipTable *sh = hipTableShard(t, s);
-            if (sel.count[s] && pqps_upload(sh->ctx, sh->ids_dev, sub_ids[s], sel.count[s] * sizeof **sub_ids, NULL) != PQPS_OK)
+        for (int s = 0; s < n_shards && rc == 0; s++)
+            if (q.count[s] && pqps_upload(lane_copy_ctx(&q, s), query_lane(&q, s)->ids_dev, sub_ids[s], q.count[s] * sizeof **sub_ids, NULL) != PQPS_OK)
                 rc = engine_error("ID upload");
-        }
         for (int s = 0; s < n_shards; s++) free(sub_ids[s]);
+        free(merged);
         tmp = malloc((biggest ? biggest : 1) * 8);
         if (!tmp) rc = -1;
     }
     for (int s = 0; s < n_shards && rc == 0; s++)
-        if (sel.count[s] && pqps_malloc(hipTableShard(t, s)->ctx, sel.count[s] * 8, &gathered[s]) != PQPS_OK) rc = engine_error("projection buffer");
+        if (q.count[s] && pqps_malloc(hipTableShard(t, s)->ctx, q.count[s] * 8, &gathered[s]) != PQPS_OK) rc = engine_error("projection buffer");
     for (int j = 0; j < numSelectItems && rc == 0; j++) {
         res->columnNames[j] = strdup(selectItems[j]);
         const int c = hipColumnId(selectItems[j]);
         res->columnKinds[j] = c < 0 ? -1 : schema.col[c].kind;
         if (c < 0 || count == 0) continue;
         const uint32_t w = t->col[c].width;
+        if (w == 0) {                                                    /* a single-valued string column: every row carries code 0 */
+            res->values[j] = calloc(count, sizeof(uint32_t));
+            if (!res->values[j]) { fprintf(stderr, "HIP engine: out of memory for the result set\n"); rc = -1; break; }
+            rc = own_dictionary(res, j, &t->dict[c], 4, count);
+            continue;
+        }
         char *raw = malloc(count * w);
         if (!raw) { fprintf(stderr, "HIP engine: out of memory for the result set\n"); rc = -1; break; }
         res->values[j] = raw;
-        rc = project_column(t, &sel, c, gathered, sub_pos, raw, tmp);
+        rc = project_column(&q, c, gathered, scattered, sub_pos, raw, tmp);
         if (rc == 0 && schema.col[c].kind == HIPKIND_DICT)
             rc = own_dictionary(res, j, &t->dict[c], w, count);
     }
@@ -581,8 +775,9 @@ static int select_columnar(struct engineS *engine, struct hipTable *t, const cha
         free(sub_pos[s]);
     }
     free(tmp);
-    free(sel.merged);
     res->numRecords = (int)count;
+    query_free(&q);
+    hipTableReleaseLane(t, q.lane);
     return rc;
 }
 
@@ -603,10 +798,8 @@ struct hipColumnarResult *executeQuerySelectColumnarHIP(struct engineS *engine, 
 
     const double t0 = now_seconds();
     hipTableLockShared(t);
-    hipTableLockDevice(t);
     const int rc = select_columnar(engine, t, selectItems, numSelectItems, whereClause, res);
-    hipTableUnlockDevice(t);
-    hipTableUnlock(t);
+    hipTableUnlockShared(t);
     res->queryTime = now_seconds() - t0;
     res->success = rc == 0;
     if (rc != 0) res->numRecords = 0;
@@ -667,6 +860,19 @@ void freeResultSetHead(struct resultSetS *head, int rows) {
     freeResultSet(head);
 }
 
+/* executeQuerySelectHIP on an engine without host rows: the same strings, made from values gathered on the device. */
+static struct resultSetS *select_device_only(struct engineS *engine, const char **selectItems, int numSelectItems, struct whereClauseS *whereClause) {
+    struct hipColumnarResult *res = executeQuerySelectColumnarHIP(engine, selectItems, numSelectItems, whereClause);
+    struct resultSetS *rs = res && res->success ? hipColumnarHead(res, 0) : NULL;      /* every row */
+    if (!rs) {
+        rs = calloc(1, sizeof *rs);
+        if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
+        rs->success = false;
+    }
+    if (res) freeColumnarResultHIP(res);
+    return rs;
+}
+
 /* freeResultSet, S:881-908. */
 void freeResultSet(struct resultSetS *result) {
     if (!result) return;
@@ -711,15 +917,19 @@ static pqps_ctx *adhoc_ctx(void) {
 }
 
 static int adhoc_search(struct hipTable *t, record **records, struct whereClauseS *whereClause, record ***out, int *matching) {
-    struct selection sel;
     struct engineS none;                                /* no indexes: always the scan path */
     memset(&none, 0, sizeof none);
-    if (run_selection(&none, t, whereClause, &sel) != 0) return -1;
-    const uint64_t count = sel.total;
+    struct query q;
+    query_init(&q, &none, t, -1, false);                /* a table without lanes: its own context and buffers */
+    int rc = query_issue(&q, whereClause);
+    if (rc == 0) rc = query_await(&q);
+    const uint64_t count = rc == 0 ? q.total : 0;
     uint32_t *ids = malloc((count ? count : 1) * sizeof *ids);
     record **hit = malloc((count ? count : 1) * sizeof *hit);
-    if (!ids || !hit) { free(ids); free(hit); fprintf(stderr, "HIP engine: out of memory for results\n"); return -1; }
-    if (count && pqps_download(t->ctx, ids, t->ids_dev, count * sizeof *ids, NULL) != PQPS_OK) { free(ids); free(hit); return engine_error("ID download"); }
+    if (rc == 0 && (!ids || !hit)) { fprintf(stderr, "HIP engine: out of memory for results\n"); rc = -1; }
+    if (rc == 0 && count && pqps_download(q.ids_ctx, ids, q.ids_dev, count * sizeof *ids, NULL) != PQPS_OK) rc = engine_error("ID download");
+    query_free(&q);
+    if (rc != 0) { free(ids); free(hit); return -1; }
     for (uint64_t i = 0; i < count; i++) hit[i] = records[ids[i]];
     free(ids);
     *out = hit;
@@ -781,6 +991,54 @@ struct engineS *initializeEngineHIP(int num_indexes, const char *indexed_attribu
     return engine;
 }
 
+/* An engine without host rows: all_records NULL, datafile "" (no CSV is kept in step). */
+static struct engineS *engine_shell(unsigned long long num_rows, const char *tableName) {
+    if (num_rows > (unsigned long long)INT_MAX) {
+        fprintf(stderr, "HIP engine: %llu rows: the engine API counts rows in int (include/executeEngine-serial.h:22)\n", num_rows);
+        return NULL;
+    }
+    struct engineS *engine = malloc(sizeof *engine);
+    if (!engine) { perror("Failed to allocate memory for engine"); exit(EXIT_FAILURE); }
+    memset(engine, 0, sizeof *engine);
+    engine->tableName = strdup(tableName ? tableName : "");
+    engine->datafile = strdup("");
+    engine->num_records = (int)num_rows;
+    return engine;
+}
+
+static void engine_indexes(struct engineS *engine, int num_indexes, const char *indexed_attributes[], const int attribute_types[]) {
+    for (int i = 0; i < num_indexes; i++)
+        if (!makeIndexHIP(engine, indexed_attributes[i], attribute_types[i]))
+            fprintf(stderr, "Failed to create index for attribute: %s\n", indexed_attributes[i]);
+}
+
+struct engineS *initializeEngineColumnsHIP(unsigned long long num_rows, const struct hipColumnData columns[12],
+                                           int num_indexes, const char *indexed_attributes[], const int attribute_types[],
+                                           const char *tableName) {
+    if (!columns) return NULL;
+    struct engineS *engine = engine_shell(num_rows, tableName);
+    if (!engine) return NULL;
+    const double t0 = now_seconds();
+    buildDeviceTableFromColumnsHIP(engine, num_rows, columns);      /* exits loudly without a GPU */
+    const double t1 = now_seconds();
+    engine_indexes(engine, num_indexes, indexed_attributes, attribute_types);
+    TRACE("init (columns): %llu rows, device columns %.1f ms, %d indexes %.1f ms\n", num_rows, (t1 - t0) * 1e3, num_indexes, (now_seconds() - t1) * 1e3);
+    return engine;
+}
+
+struct engineS *initializeEngineSyntheticHIP(unsigned long long num_rows, unsigned long long seed,
+                                             int num_indexes, const char *indexed_attributes[], const int attribute_types[],
+                                             const char *tableName) {
+    struct engineS *engine = engine_shell(num_rows, tableName);
+    if (!engine) return NULL;
+    const double t0 = now_seconds();
+    buildSyntheticDeviceTableHIP(engine, num_rows, seed);           /* exits loudly without a GPU */
+    const double t1 = now_seconds();
+    engine_indexes(engine, num_indexes, indexed_attributes, attribute_types);
+    TRACE("init (synthetic): %llu rows, generation %.1f ms, %d indexes %.1f ms\n", num_rows, (t1 - t0) * 1e3, num_indexes, (now_seconds() - t1) * 1e3);
+    return engine;
+}
+
 void destroyEngineHIP(struct engineS *engine) {
     if (!engine) { fprintf(stderr, "Attempted to destroy a NULL engine pointer\n"); return; }
     const double t_destroy = now_seconds();
@@ -803,7 +1061,7 @@ bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const c
     (void)tableName;
     hipTableLockExclusive(engine->record_block);
     const bool ok = makeIndexHIP(engine, attributeName, attributeType);
-    hipTableUnlock(engine->record_block);
+    hipTableUnlockExclusive(engine->record_block);
     return ok;
 }
 
@@ -813,7 +1071,7 @@ int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capaci
     hipTableLockShared(t);
     const int n = hipTableShards(t);
     for (int s = 0; rows && s < n && s < capacity; s++) rows[s] = hipTableShard(t, s)->n_rows;
-    hipTableUnlock(t);
+    hipTableUnlockShared(t);
     return n;
 }
 
@@ -915,6 +1173,19 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     const double t0 = now_seconds();
     hipTableLockExclusive(t);
     const size_t n = (size_t)engine->num_records;
+    if (t->device_only) {
+        /* no host rows, no CSV: the row goes to the device table alone */
+        if (n + 1 > (size_t)INT_MAX) { hipTableUnlockExclusive(t); return false; }
+        engine->num_records = (int)(n + 1);
+        const bool ok = appendRowDeviceTableHIP(engine, r);
+        if (!ok) {
+            engine->num_records = (int)n;
+            fprintf(stderr, "HIP engine: INSERT needs a table rebuild (head-room used up or a dictionary outgrowing its code width), which an engine without host rows cannot do\n");
+        }
+        TRACE("INSERT (device only): %.3f ms\n", (now_seconds() - t0) * 1e3);
+        hipTableUnlockExclusive(t);
+        return ok;
+    }
     /* room for the row first: a failed allocation must not leave the CSV one row ahead of the engine.
      * The host row store grows geometrically; all_records[] is re-pointed only when the block moved */
     if (n + 1 > t->row_capacity) {
@@ -926,11 +1197,11 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
         }
         record **rows = block ? realloc(engine->all_records, cap * sizeof *rows) : NULL;
         if (rows) engine->all_records = rows;
-        if (!block || !rows) { hipTableUnlock(t); return false; }
+        if (!block || !rows) { hipTableUnlockExclusive(t); return false; }
         t->row_capacity = cap;
     }
     FILE *f = fopen(engine->datafile, "a");
-    if (!f) { hipTableUnlock(t); return false; }
+    if (!f) { hipTableUnlockExclusive(t); return false; }
     write_csv_row(f, r);
     fclose(f);
 
@@ -938,37 +1209,60 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
     engine->all_records[n] = &t->row_block[n];
     engine->num_records = (int)(n + 1);
     const double t1 = now_seconds();
-    appendRowDeviceTableHIP(engine);
+    appendRowDeviceTableHIP(engine, engine->all_records[n]);
     TRACE("INSERT: CSV append + host row %.3f ms, device append + indexes %.3f ms\n", (t1 - t0) * 1e3, (now_seconds() - t1) * 1e3);
-    hipTableUnlock(t);
+    hipTableUnlockExclusive(t);
     return true;
 }
 
 /* executeQueryDeleteSerial, S:627-715: the per-row decision is the GPU flag
  * kernel (the flag-array shape of engine/omp/executeEngine-omp.c:708-732). */
-/* Flags of the rows that go, per shard on the device and for the whole table on the host. */
-static int delete_flags(struct hipTable *t, struct whereClauseS *whereClause, size_t n, uint8_t **flags_dev, uint8_t *flags) {
-    struct hipPlan plan;
-    if (bind_where(t, whereClause, &plan) != 0) return -1;
-    const int n_shards = hipTableShards(t);
-    struct shard_pred sp[HIP_MAX_SHARDS];
-    memset(sp, 0, sizeof sp);
+/* Flags of the rows that go, per shard on the device; `flags` (may be NULL: an engine without host rows) receives them
+ * for the whole table, *deleted their number. */
+static int delete_flags(struct engineS *engine, struct hipTable *t, struct whereClauseS *whereClause, size_t n, uint8_t **flags_dev, uint8_t *flags,
+                        uint64_t *deleted) {
+    struct query q;
+    query_init(&q, engine, t, -1, true);                            /* the writer is alone: the table's own context and buffers */
+    *deleted = 0;
+    if (bind_where(t, whereClause, &q.plan) != 0) return -1;
+    q.have_plan = true;
     int rc = 0;
-    for (int s = 0; s < n_shards && rc == 0; s++) {
+    for (int s = 0; s < q.n_shards && rc == 0; s++) {
         struct hipTable *sh = hipTableShard(t, s);
-        rc = shard_pred_prepare(sh, &plan, &sp[s]);
+        /* the passes in front of the last as for any query, the last pass as flags instead of a count */
+        struct hipPlan head = q.plan;
+        struct shard_pred *sp = &q.sp[s];
+        memset(sp, 0, sizeof *sp);
+        const struct hipPass *last = &head.pass[head.n_passes - 1];
+        if (head.n_passes > 1) {
+            sp->flags = calloc((size_t)head.n_passes - 1, sizeof *sp->flags);
+            if (!sp->flags) { rc = -1; break; }
+            sp->n_flags = head.n_passes - 1;
+            for (int k = 0; k < sp->n_flags && rc == 0; k++) {
+                pqps_column cols[PQPS_MAX_COLUMNS];
+                if (pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&sp->flags[k]) != PQPS_OK) { rc = engine_error("flag allocation"); break; }
+                pass_columns(sh, &head.pass[k], sp->flags, cols);
+                if (pqps_filter_flags(sh->ctx, cols, head.pass[k].pred.n_columns, sh->n_rows, &head.pass[k].pred, sp->flags[k], sh->own.count_dev + 4, NULL) != PQPS_OK)
+                    rc = engine_error("flag filter");
+            }
+        }
+        sp->pred = &last->pred;
+        sp->n_cols = last->pred.n_columns;
+        pass_columns(sh, last, sp->flags, sp->cols);
         if (rc == 0 && pqps_malloc(sh->ctx, sh->capacity_rows, (void **)&flags_dev[s]) != PQPS_OK) rc = engine_error("flag allocation");
-        if (rc == 0 && pqps_filter_flags(sh->ctx, sp[s].cols, sp[s].n_cols, sh->n_rows, sp[s].pred, flags_dev[s], sh->count_dev, NULL) != PQPS_OK)
+        if (rc == 0 && pqps_filter_flags(sh->ctx, sp->cols, sp->n_cols, sh->n_rows, sp->pred, flags_dev[s], sh->own.count_dev, NULL) != PQPS_OK)
             rc = engine_error("flag filter");
     }
-    for (int s = 0; s < n_shards; s++) {
+    for (int s = 0; s < q.n_shards; s++) {
         struct hipTable *sh = hipTableShard(t, s);
+        uint64_t k = 0;
         if (rc == 0 && pqps_ctx_sync(sh->ctx, NULL) != PQPS_OK) rc = engine_error("filter execution");
-        if (rc == 0 && sh->row0 + sh->n_rows > n) { fprintf(stderr, "HIP engine: device shards hold more rows than the host\n"); rc = -1; }
-        if (rc == 0 && sh->n_rows && pqps_download(sh->ctx, flags + sh->row0, flags_dev[s], sh->n_rows, NULL) != PQPS_OK) rc = engine_error("flag download");
-        shard_pred_free(sh, &sp[s]);
+        if (rc == 0 && pqps_download(sh->ctx, &k, sh->own.count_dev, sizeof k, NULL) != PQPS_OK) rc = engine_error("count download");
+        *deleted += k;
+        if (rc == 0 && sh->row0 + sh->n_rows > n) { fprintf(stderr, "HIP engine: device shards hold more rows than the engine\n"); rc = -1; }
+        if (rc == 0 && flags && sh->n_rows && pqps_download(sh->ctx, flags + sh->row0, flags_dev[s], sh->n_rows, NULL) != PQPS_OK) rc = engine_error("flag download");
     }
-    hipPlanFree(&plan);
+    query_free(&q);
     return rc;
 }
 
@@ -984,33 +1278,42 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     const int n_shards = hipTableShards(t);
     uint8_t *flags_dev[HIP_MAX_SHARDS];
     memset(flags_dev, 0, sizeof flags_dev);
-    uint8_t *flags = malloc(n ? n : 1);
-    if (!flags || delete_flags(t, whereClause, n, flags_dev, flags) != 0) {
-        if (!flags) fprintf(stderr, "HIP engine: out of memory for %zu delete flags\n", n);
+    uint8_t *flags = t->device_only ? NULL : malloc(n ? n : 1);
+    uint64_t flagged = 0;
+    if ((!flags && !t->device_only) || delete_flags(engine, t, whereClause, n, flags_dev, flags, &flagged) != 0) {
+        if (!flags && !t->device_only) fprintf(stderr, "HIP engine: out of memory for %zu delete flags\n", n);
         for (int s = 0; s < n_shards; s++) if (flags_dev[s]) pqps_free(hipTableShard(t, s)->ctx, flags_dev[s]);
         free(flags);
-        hipTableUnlock(t);
+        hipTableUnlockExclusive(t);
         rs->success = false;                                       /* nothing was deleted */
         return rs;
     }
     const double t1 = now_seconds();
 
     size_t keep = 0, deleted = 0;
-    record *block = t->row_block;
-    for (size_t i = 0; i < n; i++) {
-        if (flags[i]) { deleted++; continue; }
-        if (keep != i) block[keep] = block[i];
-        keep++;
+    if (t->device_only) {                                           /* no host rows, no CSV */
+        deleted = (size_t)flagged;
+        keep = n - deleted;
+        engine->num_records = (int)keep;
+    } else {
+        record *block = t->row_block;
+        for (size_t i = 0; i < n; i++) {
+            if (flags[i]) { deleted++; continue; }
+            if (keep != i) block[keep] = block[i];
+            keep++;
+        }
+        free(flags);
+        for (size_t i = 0; i < keep; i++) engine->all_records[i] = &block[i];
+        engine->num_records = (int)keep;
     }
-    free(flags);
-    for (size_t i = 0; i < keep; i++) engine->all_records[i] = &block[i];
-    engine->num_records = (int)keep;
     const double t2 = now_seconds();
 
-    FILE *f = fopen(engine->datafile, "w");                       /* S:683-701: no header written */
-    if (f) {
-        write_csv_table(f, block, keep);
-        fclose(f);
+    if (!t->device_only) {
+        FILE *f = fopen(engine->datafile, "w");                   /* S:683-701: no header written */
+        if (f) {
+            write_csv_table(f, t->row_block, keep);
+            fclose(f);
+        }
     }
     const double t3 = now_seconds();
     /* device side: the same flags compact the 12 columns of every shard in place (order kept); dictionaries
@@ -1019,7 +1322,7 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     for (int s = 0; s < n_shards; s++) pqps_free(hipTableShard(t, s)->ctx, flags_dev[s]);
     TRACE("DELETE: %zu of %zu rows, flags %.3f ms, host rows %.3f ms, CSV rewrite %.3f ms, device compaction + indexes %.3f ms\n",
           deleted, n, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (now_seconds() - t3) * 1e3);
-    hipTableUnlock(t);
+    hipTableUnlockExclusive(t);
     rs->numRecords = (int)deleted;
     rs->queryTime = now_seconds() - t0;
     rs->success = true;

@@ -114,9 +114,20 @@ static const struct hipColumnInfo *col_info(const struct hipSchema *schema, int 
     return col >= PQPS_MAX_COLUMNS ? &k_flag_column : &schema->col[col];
 }
 
-static int attribute_column(const char *attribute) {
-    if (attribute && attribute[0] == FLAG_ATTRIBUTE) return PQPS_MAX_COLUMNS + atoi(attribute + 1);
-    return hipColumnId(attribute);
+/* Flag leaves exist only inside hipCompileWherePlan: the planner makes them (make_flag_leaf: the name "\x01<pass>" AND
+ * the mark in value_type), and only passes that exist can be named -- `flag_passes` = the passes emitted so far
+ * while the planner runs on the calling thread, 0 otherwise.  A caller-supplied list that names "\x01<n>" (the engine
+ * API takes whereClauseS lists from anybody) is an unknown attribute like any other, never an index into flag
+ * buffers that do not exist. */
+#define FLAG_MARK 0x7F1A6
+static _Thread_local int flag_passes;
+
+static int node_column(const struct whereClauseS *c) {
+    if (c->attribute && c->attribute[0] == FLAG_ATTRIBUTE) {
+        const int pass = atoi(c->attribute + 1);
+        return c->value_type == FLAG_MARK && pass >= 0 && pass < flag_passes ? PQPS_MAX_COLUMNS + pass : -1;
+    }
+    return hipColumnId(c->attribute);
 }
 
 struct builder {
@@ -138,7 +149,7 @@ static int count_leaves(const struct whereClauseS *wc) {
 static void make_leaf(struct builder *b, struct step *s, const struct whereClauseS *c) {
     s->kind = ST_FALSE;
     s->col = -1;
-    const int col = attribute_column(c->attribute);
+    const int col = node_column(c);
     const int op = op_code(c->operator);
     if (col < 0 || op < 0 || c->value == NULL) return;          /* S:212, S:279: never true */
     const struct hipColumnInfo *ci = col_info(b->schema, col);
@@ -156,8 +167,12 @@ static void make_leaf(struct builder *b, struct step *s, const struct whereClaus
         else if (op == 1) { s->kind = ST_LEAF; s->lo = (uint64_t)lit; s->span = 0; s->neg = 1; }
         else return;                                             /* S:207-210: no ordering comparators */
     } else {
-        if (ci->present && ci->kind == HIPKIND_DICT) window_dict(s, op, c->value, ci);
-        else s->kind = ST_LEAF;                                  /* reported as absent below */
+        if (ci->present && ci->kind == HIPKIND_DICT) {
+            window_dict(s, op, c->value, ci);
+            /* a column with ONE value: every row carries code 0, the comparison is decided here and now (such a column
+             * may have no device buffer at all: include/buildEngine-hip.h) */
+            if (s->kind == ST_LEAF && ci->dict_count == 1) s->kind = ((s->lo == 0) != (s->neg != 0)) ? ST_TRUE : ST_FALSE;
+        } else s->kind = ST_LEAF;                                /* reported as absent below */
     }
     if (s->kind == ST_LEAF && !ci->present) {
         b->failed = 1;
@@ -343,7 +358,7 @@ static void *plan_alloc(struct planner *P, size_t bytes) {
 static void chain_columns(const struct whereClauseS *wc, uint32_t *table_mask, int *flag_columns) {
     for (; wc; wc = wc->next) {
         if (wc->sub) { chain_columns(wc->sub, table_mask, flag_columns); continue; }
-        const int col = attribute_column(wc->attribute);
+        const int col = node_column(wc);
         if (col >= PQPS_MAX_COLUMNS) *flag_columns += 1;
         else if (col >= 0) *table_mask |= 1u << col;
     }
@@ -359,7 +374,7 @@ static int span_fits(const struct whereClauseS *first, const struct whereClauseS
         leaves += element_leaves(e);
         if (e->sub) chain_columns(e->sub, &mask, &flags);
         else {
-            const int col = attribute_column(e->attribute);
+            const int col = node_column(e);
             if (col >= PQPS_MAX_COLUMNS) flags++; else if (col >= 0) mask |= 1u << col;
         }
     }
@@ -376,7 +391,9 @@ static int emit_pass(struct planner *P, const struct whereClauseS *chain) {
         plan->pass = grown; P->capacity = cap;
     }
     struct hipPass *pass = &plan->pass[plan->n_passes];
+    flag_passes = plan->n_passes;                                  /* this pass may read the flags of the passes before it */
     if (hipCompileWhere(P->schema, chain, &pass->pred, pass->column_ids, P->err, P->errlen) != 0) return -1;
+    flag_passes = plan->n_passes + 1;                              /* the planner may now name this pass's flags */
     return plan->n_passes++;
 }
 
@@ -387,6 +404,7 @@ static int make_flag_leaf(struct planner *P, struct whereClauseS *e, int pass) {
     e->attribute = name;
     e->operator = "=";
     e->value = "1";
+    e->value_type = FLAG_MARK;
     e->sub = NULL;
     return 0;
 }
@@ -438,11 +456,13 @@ int hipCompileWherePlan(const struct hipSchema *schema, const struct whereClause
     memset(&P, 0, sizeof P);
     P.schema = schema; P.plan = plan; P.err = err; P.errlen = errlen;
     /* one pass whenever the clause allows it (constant leaves are folded away first) */
+    flag_passes = 0;
     if (count_leaves(where) <= MAX_RAW_STEPS && emit_pass(&P, where) == 0) return 0;
     if (err && errlen) err[0] = '\0';
     plan->n_passes = 0;
     struct whereClauseS *fitted = fit_chain(&P, where);
     const int last = fitted ? emit_pass(&P, fitted) : -1;
+    flag_passes = 0;
     for (int i = 0; i < P.n_arena; i++) free(P.arena[i]);
     free(P.arena);
     if (last < 0) { hipPlanFree(plan); return -1; }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--count", action="store_true", help="also time COUNT(*) of the same predicates")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--copies", type=int, default=1, help="table copies the launches alternate between (2: nothing a launch reads is cache-resident)")
     ap.add_argument("--wall", action="store_true", help="also report wall time per query of a back-to-back stream")
     args = ap.parse_args()
     pq, _ = bench.load_pkg()
@@ -32,17 +33,21 @@ def main():
     ctx = pq.Context(0)
     names = args.queries.split(",")
     needed = {leaf[0] for k in names for leaf in bench._leaves(bench.QUERIES[k][0])}
-    table = pq.SyntheticTable(ctx, args.rows, seed=0x5EED, columns=sorted(needed))
+    tables = [pq.SyntheticTable(ctx, args.rows, seed=0x5EED, columns=sorted(needed)) for _ in range(max(1, args.copies))]
     n = args.rows
     ids = ctx.malloc(4 * max(n // 2, 1024))
     cnt = ctx.malloc(64)
     out = []
     for name in names:
         chain, _sql = bench.QUERIES[name]
-        pred, cols, nc, bpr = table.bind(chain)
+        bound = [t.bind(chain) for t in tables]
+        bpr = bound[0][3]
+        turn = [0]
         modes = ["ids"] + (["count"] if args.count else [])
         for mode in modes:
             def run():
+                pred, cols, nc, _ = bound[turn[0] % len(bound)]
+                turn[0] += 1
                 if mode == "ids":
                     pq.check(L.pqps_filter_scan(ctx.h, cols, nc, n, 0, C.byref(pred), ids, n // 2, cnt, None))
                 else:
@@ -60,7 +65,7 @@ def main():
             us = tot / k * 1e3
             byts = n * bpr + (4 * m.value if mode == "ids" else 8)
             frac = byts / (us * 1e-6) / 8e12
-            s = f"{name}/{mode}: {us:7.1f} us  frac {frac:.3f}  ({m.value} matches)"
+            s = f"{name}/{mode}: {us:7.1f} us (scan kernel {ev / k * 1e3:.1f})  frac {frac:.3f}  ({m.value} matches)"
             if args.wall:
                 ctx.sync()
                 t0 = time.perf_counter()

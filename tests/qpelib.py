@@ -354,7 +354,7 @@ ORC_STR = ["raw_command", "base_command", "shell_type", "timestamp", "working_di
 class HostSynth:
     """Host copy of rows [row0, row0+n) of the synthetic table (numpy arrays), same bits as the device."""
 
-    def __init__(self, n, seed=0x5EED, row0=0):
+    def __init__(self, n, seed=0x5EED, row0=0, full=False):
         import numpy as np
         self.n, self.seed, self.row0 = n, seed, row0
         L = pq.lib()
@@ -371,10 +371,24 @@ class HostSynth:
         for k in self.arr:
             self.arr[k] = self.arr[k][:n]
         self._dicts = {}
-        for name, vals in (("shell_type", pq.SYNTH_SHELLS), ("user_name", pq.SYNTH_USERS_DICT),
-                           ("host_name", pq.SYNTH_HOSTS), ("base_command", pq.SYNTH_BASES)):
+        self.values = {"shell_type": pq.SYNTH_SHELLS, "user_name": pq.SYNTH_USERS_DICT, "host_name": pq.SYNTH_HOSTS,
+                       "base_command": pq.SYNTH_BASES}
+        if full:                                        # the single-valued columns of the synthetic ENGINE table
+            for name, value in pq.SYNTH_CONSTANTS.items():
+                self.arr[name] = np.zeros(n, dtype=np.uint8)
+                self.values[name] = [value]
+        for name, vals in self.values.items():
             arr = (C.c_char_p * len(vals))(*vals)
             self._dicts[name] = arr
+
+    def cell(self, row, column):
+        """Text of one cell as get_attribute_string_value (serial:216-248) prints it."""
+        v = self.arr[column][row]
+        if column in self.values:
+            return self.values[column][int(v)].decode("latin-1")
+        if column == "sudo_used":
+            return "true" if v else "false"
+        return str(int(v))
 
     def orc_columns(self):
         oc = OrcColumns()

@@ -6,6 +6,8 @@ import pathlib
 import re
 import subprocess
 
+import pytest
+
 import qpelib as q
 
 PROBE = r"""
@@ -44,6 +46,77 @@ def test_struct_layouts_match_reference(tmp_path):
     logic_off, ncond_off, pred_size, leaf_size = map(int, out[2].split())
     assert ncond_off == logic_off + 16          # logic_ops[4] aliases num_conditions (parser quirk)
     assert pred_size == C.sizeof(q.pq.Predicate) and leaf_size == C.sizeof(q.pq.Leaf)
+
+
+REFERENCE_INCLUDE = pathlib.Path("/root/reference/include")
+# what only this repository has: the HIP engine's own headers (everything else of include/ restates a reference header)
+HIP_ONLY_HEADERS = ["executeEngine-hip.h", "buildEngine-hip.h", "hipPredicate.h", "pqps_hip.h"]
+
+SHARED_PROBE = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "executeEngine-serial.h"
+#include "connectEngine.h"
+#include "printHelper.h"
+#include "bplus.h"
+#include "sql.h"
+#define F(T, f) printf(#T "." #f " %zu %zu\n", offsetof(T, f), sizeof(((T *)0)->f))
+int main(void) {
+    printf("sizes %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(record), sizeof(struct engineS), sizeof(struct resultSetS),
+           sizeof(struct whereClauseS), sizeof(KEY_T), sizeof(node), sizeof(ParsedSQL), sizeof(Token), sizeof(Condition), sizeof(FieldInfo));
+    F(record, command_id); F(record, raw_command); F(record, base_command); F(record, shell_type); F(record, exit_code);
+    F(record, timestamp); F(record, sudo_used); F(record, working_directory); F(record, user_id); F(record, user_name);
+    F(record, host_name); F(record, risk_level);
+    F(struct engineS, tableName); F(struct engineS, bplus_tree_roots); F(struct engineS, num_indexes); F(struct engineS, indexed_attributes);
+    F(struct engineS, attribute_types); F(struct engineS, all_records); F(struct engineS, num_records); F(struct engineS, datafile);
+    F(struct engineS, record_block);
+    F(struct resultSetS, numRecords); F(struct resultSetS, numColumns); F(struct resultSetS, columnNames); F(struct resultSetS, columnTypes);
+    F(struct resultSetS, data); F(struct resultSetS, queryTime); F(struct resultSetS, success);
+    F(struct whereClauseS, attribute); F(struct whereClauseS, operator); F(struct whereClauseS, value); F(struct whereClauseS, value_type);
+    F(struct whereClauseS, next); F(struct whereClauseS, logical_op); F(struct whereClauseS, sub);
+    F(ParsedSQL, command); F(ParsedSQL, table); F(ParsedSQL, columns); F(ParsedSQL, num_columns); F(ParsedSQL, conditions);
+    F(ParsedSQL, logic_ops); F(ParsedSQL, num_conditions);
+    F(Condition, column); F(Condition, op); F(Condition, value); F(Condition, is_numeric);
+    F(Token, type); F(Token, value);
+    printf("enums %d %d %d %d %d %d\n", (int)FIELD_UINT64, (int)FIELD_INT, (int)FIELD_STRING, (int)FIELD_BOOL, MAX_TOKENS, ROW_LIMIT);
+    return 0;
+}
+"""
+
+
+def _run_probe(tmp_path, name, include_dirs):
+    src = tmp_path / f"{name}.c"
+    src.write_text(SHARED_PROBE)
+    exe = tmp_path / name
+    subprocess.run(["gcc", "-std=c11", *[f"-I{d}" for d in include_dirs], str(src), "-o", str(exe)], check=True)
+    return subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+
+
+@pytest.mark.skipif(not REFERENCE_INCLUDE.exists(), reason="the reference tree exists in the authoring container only")
+def test_struct_layouts_equal_the_reference_headers_themselves(tmp_path):
+    """The same probe compiled against /root/reference/include and against include/: every size, every field offset
+    and width of the contract structs, the enum values and the two macros the bridge uses."""
+    ours = _run_probe(tmp_path, "ours", [q.ROOT / "include"])
+    theirs = _run_probe(tmp_path, "theirs", [REFERENCE_INCLUDE])
+    assert ours == theirs
+    assert ours.splitlines()[0].split()[1:] == "1040 72 48 56 16 40 6336 260 336 24".split()
+
+
+@pytest.mark.skipif(not REFERENCE_INCLUDE.exists(), reason="the reference tree exists in the authoring container only")
+def test_engine_sources_compile_against_the_reference_headers(tmp_path):
+    """engine/hip/*.c drop into the reference's tree -- they compile against the REFERENCE's own
+    headers (executeEngine-serial.h, bplus.h, recordSchema.h, logType.h, sql.h ...) plus the four headers only this
+    repository has.  -Werror: a prototype that drifted from the reference's would be a conflicting declaration."""
+    hip_only = tmp_path / "hip_only"
+    hip_only.mkdir()
+    for h in HIP_ONLY_HEADERS:
+        (hip_only / h).write_text((q.ROOT / "include" / h).read_text())
+    sources = sorted((q.PKG / "engine" / "hip").glob("*.c"))
+    assert len(sources) >= 3
+    for src in sources:
+        p = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-Wno-stringop-truncation", f"-I{REFERENCE_INCLUDE}", f"-I{hip_only}", str(src)],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, (src.name, p.stderr[-2000:])
 
 
 def _declared_functions(header):

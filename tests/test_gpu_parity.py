@@ -292,7 +292,7 @@ def test_query_stream_keeps_queries_apart(ctx):
     bound = {k: dev.bind(QUERIES[k]) for k in names}
     qs = C.c_void_p()
     pq.check(L.pqps_qstream_create(ctx.h, 3, C.byref(qs)), "pqps_qstream_create")
-    assert L.pqps_qstream_create(ctx.h, 1, C.byref(C.c_void_p())) == -1           # depth >= 2
+    assert L.pqps_qstream_create(ctx.h, 0, C.byref(C.c_void_p())) == -1           # depth >= 1
     outs = [DeviceOut(ctx, n) for _ in range(8)]
     counts = ctx.malloc(8 * 8)
     try:
@@ -378,7 +378,9 @@ def test_shim_rejects_malformed_calls(ctx):
     assert L.pqps_compact_rows(ctx.h, cols, 0, 10, out.ids, C.byref(C.c_uint64()), None) == EINVAL
     assert L.pqps_exchange_select(None, cols, nc, 10, 0, C.byref(pred), 0, None) == EINVAL
     assert L.pqps_qstream_scan(None, cols, nc, 10, 0, C.byref(pred), out.ids, out.cap, out.count, None) == EINVAL
-    assert L.pqps_qstream_create(ctx.h, 17, C.byref(C.c_void_p())) == EINVAL and L.pqps_qstream_create(None, 2, C.byref(C.c_void_p())) == EINVAL
+    assert L.pqps_qstream_create(ctx.h, 65, C.byref(C.c_void_p())) == EINVAL and L.pqps_qstream_create(None, 2, C.byref(C.c_void_p())) == EINVAL
+    assert L.pqps_qstream_wait(None, 0) == EINVAL and L.pqps_qstream_mark(None, 0) == EINVAL
+    assert L.pqps_copy_peer(None, out.ids, ctx.h, out.ids, 4, None) == EINVAL
     assert L.pqps_project_column(ctx.h, cols, None, out.count, 10, 0, out.ids, None) == EINVAL
     assert L.pqps_project_column(ctx.h, cols, out.ids, out.count, 10, 0, None, None) == EINVAL
     assert L.pqps_gather_keys(ctx.h, cols, 1, out.ids, out.count, 10, 0, None, None) == EINVAL
