@@ -73,28 +73,43 @@ def cpu_baseline(pq, chain, sql, seed, log):
     sys.path.insert(0, str(ROOT / "tests"))
     import qpelib as q
 
+    import statistics
     ncores = os.cpu_count() or 1
-    out = {}
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     n_col = 20_000_000
     host = q.HostSynth(n_col, seed=seed)
-    t0 = time.perf_counter()
-    k1 = len(host.oracle_scan(chain, nthreads=1))
-    t_port = time.perf_counter() - t0
+
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            k = fn()
+            ts.append(time.perf_counter() - t0)
+        return k, statistics.median(ts), min(ts)
+
+    k1, t_port, t_port_best = timed(lambda: len(host.oracle_scan(chain, nthreads=1)), 3)
     nth = min(ncores, 64)
-    t0 = time.perf_counter()
-    k2 = len(host.oracle_scan(chain, nthreads=nth))
-    t_omp = time.perf_counter() - t0
+    k2, t_omp, t_omp_best = timed(lambda: len(host.oracle_scan(chain, nthreads=nth)), 5)
     assert k1 == k2
-    port = {"value": n_col / t_port, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"{n_col} synthetic rows (columnar), query {sql!r}, {k1} matches, oracle serial evaluator"}
-    omp = {"value": n_col / t_omp, "unit": "rows/s", "cores": nth, "kind": "port",
-           "sample": f"{n_col} rows, OpenMP row ranges x{nth}"}
-    log(f"cpu port: serial {port['value']/1e6:.1f} M rows/s, omp x{nth} {omp['value']/1e6:.1f} M rows/s")
+    # flat keys: the driver's record keeps one level of this object
+    common = {"cpu_model": cpu_model, "cores_online": ncores,
+              "port_serial_value": n_col / t_port, "port_serial_best": n_col / t_port_best,
+              "omp_value": n_col / t_omp, "omp_best": n_col / t_omp_best, "omp_cores": nth,
+              "port_sample": f"{n_col} synthetic rows (columnar), query {sql!r}, {k1} matches: the oracle's row-at-a-time evaluator, "
+                             f"serial (median of 3) and OpenMP row ranges x{nth} (median of 5)"}
+    log(f"cpu port ({cpu_model}, {ncores} cores online): serial {n_col / t_port / 1e6:.1f} M rows/s, omp x{nth} {n_col / t_omp / 1e6:.1f} M rows/s")
 
     ref = q.load_ref()
     if ref is None:
-        port["omp"] = omp
-        return port
+        return dict({"value": n_col / t_port, "best": n_col / t_port_best, "unit": "rows/s", "cores": 1, "kind": "port",
+                     "sample": common["port_sample"]}, **common)
     # the real reference over AoS records built from the same synthetic columns
     n_aos = 12_000_000
     rec_dt = np.dtype({"names": ["command_id", "raw_command", "base_command", "shell_type", "exit_code", "timestamp",
@@ -117,21 +132,20 @@ def cpu_baseline(pq, chain, sql, seed, log):
     libc = C.CDLL(None)
     libc.free.argtypes = [C.c_void_p]
     wl = pq.WhereList(chain)
-    best = None
-    for _ in range(3):
+    ts = []
+    for _ in range(5):
         cnt = C.c_int()
         t0 = time.perf_counter()
         res = ref.linearSearchRecords(ptrs.ctypes.data, n_aos, C.cast(wl.ptr, C.c_void_p), C.byref(cnt))
-        dt = time.perf_counter() - t0
+        ts.append(time.perf_counter() - t0)
         libc.free(res)
-        best = dt if best is None else min(best, dt)
+    med, best = statistics.median(ts), min(ts)
     want = int(np.searchsorted(host.oracle_scan(chain), n_aos))
     assert cnt.value == want, (cnt.value, want)
-    log(f"cpu reference (QPESeq linearSearchRecords): {n_aos / best / 1e6:.2f} M rows/s on 1 core")
-    return {"value": n_aos / best, "unit": "rows/s", "cores": 1, "kind": "reference",
-            "sample": f"{n_aos} AoS records (1040 B) of the same synthetic table, query {sql!r}, "
-                      f"reference linearSearchRecords compiled -O2, best of 3",
-            "port_serial": port, "port_omp": omp}
+    log(f"cpu reference (QPESeq linearSearchRecords): {n_aos / med / 1e6:.2f} M rows/s on 1 core (best {n_aos / best / 1e6:.2f})")
+    return dict({"value": n_aos / med, "best": n_aos / best, "unit": "rows/s", "cores": 1, "kind": "reference",
+                 "sample": f"{n_aos} AoS records (1040 B) of the same synthetic table, query {sql!r}, "
+                           f"reference linearSearchRecords compiled -O2 (oracle/_ref), median of 5"}, **common)
 
 
 def main():
@@ -155,6 +169,13 @@ def main():
                          "'torch' = torch.distributed collectives from Python (also the gloo rehearsal path)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N=1: one query at a time on one stream (no second query in flight)")
+    ap.add_argument("--level", default=None, choices=["engine", "shim"],
+                    help="where `value` is measured.  engine (default at N = 1): through the reference-facing engine API -- "
+                         "initializeEngineSyntheticHIP + executeQuery{Select,Count}AsyncHIP on the engine's query lanes, issued by a C loop "
+                         "(host/engineBench.c), no torch in the path; shim (default at N > 1): pqps_qstream_scan / pqps_exchange_select "
+                         "of include/pqps_hip.h, one level below.  The other level's figure is reported beside it.")
+    ap.add_argument("--engine-threads", type=int, default=1, help="host threads issuing queries in the engine-level leg")
+    ap.add_argument("--engine-in-flight", type=int, default=3, help="tickets each thread keeps outstanding in the engine-level leg")
     ap.add_argument("--force-merge", action="store_true",
                     help="N=1 rehearsal: run the N>1 exchange step (RCCL all-gather + merge, second stream) with a world of 1")
     args = ap.parse_args()
@@ -241,6 +262,7 @@ def main():
     pq.check(L.pqps_filter_scan(ctx.h, cols, nc, count, start, C.byref(pred), cal_ids.data_ptr(), count,
                                 cal_cnt.data_ptr(), sptr), "calibration scan")
     torch.cuda.synchronize()
+    kernel_chosen = L.pqps_last_kernel().decode()                    # what the shim launched for this query on this table (this thread's last call)
     local_matches = int(cal_cnt.item())
     max_matches = local_matches
     cdev = device if args.backend == "nccl" else torch.device("cpu")      # where small control tensors live
@@ -359,6 +381,10 @@ def main():
         step(k)
     fence()
     ring_wait_ns(1)
+    # the lanes' own recorders (events on the dispatch packets: recording does not change how the launches overlap)
+    # give the duration of every launch AS IT RAN in the timed region, next to its neighbour on the other lane
+    if qs is not None:
+        pq.check(L.pqps_qstream_set_timing(qs, 1), "pqps_qstream_set_timing")
     # ---- timed region: exactly K steps, nothing but the hot path (+ merge) enqueued -------
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -367,6 +393,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     waited = ring_wait_ns(1) * 1e-9
+    in_stream_ms = None
+    if qs is not None:
+        ev, tot, k = C.c_double(), C.c_double(), C.c_int()
+        pq.check(L.pqps_qstream_kernel_time(qs, C.byref(ev), C.byref(tot), C.byref(k)), "pqps_qstream_kernel_time")
+        pq.check(L.pqps_qstream_set_timing(qs, 0), "pqps_qstream_set_timing")
+        in_stream_ms = tot.value / max(k.value, 1)
     log(f"timed region: {elapsed / max(args.steps, 1) * 1e6:.1f} us/step; host: {(enqueued - waited) / max(args.steps, 1) * 1e6:.1f} us/step in "
         f"runtime calls + {waited / max(args.steps, 1) * 1e6:.1f} us/step waiting for a free ring slot (the GPU being the slower side)")
     # ---- same K steps again with HIP events on the dispatch of every scan kernel (ID output: the ONE launch of
@@ -424,7 +456,6 @@ def main():
 
     traffic, traffic_src = pmc_traffic(args.query, count) if (world == 1 and not count_mode) else (None, None)
     cfg_no = (4 if count_mode else 3) if strong else 1
-    nt = "true" if count * bytes_per_row > (256 << 20) else "false"
     result = {
         "metric": "rows/sec SELECT-filter on commands_* schema",
         "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -444,16 +475,43 @@ def main():
                    "device": dev_name},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": (K_NAMES.get((args.query, args.mode), "eval_spec_kernel / eval_generic_kernel").replace("NT", "NT=" + nt)
-                                + (" -- the ONE launch of an ID query: scan tiles (the only readers of the table) + expander waves"
-                                   if not count_mode else " -- the scan; the one-workgroup reduction of the totals follows it")),
+                     "kernel": (kernel_chosen if not count_mode else kernel_chosen.replace("MODE_IDS", "MODE_COUNT"))
+                               + (" -- the ONE launch of an ID query: scan tiles (the only readers of the table) + expander workgroups"
+                                  if not count_mode else " -- the scan; the one-workgroup reduction of the totals follows it"),
                      "avg_kernel_ms": avg_kernel_ms, "avg_pipeline_ms": pipe_ms / max(launches, 1),
+                     # the same launches as they ran IN the timed region (several in flight): longer each, shorter per query
+                     "in_stream_kernel_ms": in_stream_ms,
                      "launches_timed": launches, "algorithmic_bytes_per_launch": alg_bytes,
                      # the same algorithmic bytes over the TIMED region's time per step (queries as they were issued
                      # for `value`: two in flight, one's tail under the other's scan) -- per GPU
                      "job_achieved": alg_bytes / (ms_per_step * 1e-3) / 1e9,
                      "job_frac": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
     }
+
+    # ---- the same workload through the ENGINE API (the drop-in boundary the reference's drivers call) ----
+    level = args.level or ("engine" if (world == 1 and not args.force_merge) else "shim")
+    if world == 1 and not args.force_merge and not args.no_pipeline:
+        shim_level = {"value": rows_per_s, "ms_per_step": ms_per_step, "api": "pqps_qstream_%s (include/pqps_hip.h), issued from Python" % ("count" if count_mode else "scan")}
+        try:
+            eng = engine_leg(pq, chain, count, args.seed, args.steps, args.warmup, count_mode, copies, args.engine_threads, args.engine_in_flight, log)
+            result["engine_level"] = eng
+            result["shim_level"] = shim_level
+            result["config"]["level"] = level
+            if level == "engine":
+                result["value"] = eng["value"]
+                result["ms_per_step"] = eng["ms_per_query"]
+                result["roofline"]["job_achieved"] = alg_bytes / (eng["ms_per_query"] * 1e-3) / 1e9
+                result["roofline"]["job_frac"] = result["roofline"]["job_achieved"] / HBM_PEAK_GBPS
+                result["roofline"]["in_stream_kernel_ms"] = eng["in_stream_kernel_ms"]
+                result["config"]["pipelining"] = (f"{args.engine_threads} host thread(s) x {args.engine_in_flight} asynchronous tickets outstanding over {copies} engines "
+                                                  "(copies of the table, alternated); every engine runs its queries on two lanes = two HIP streams "
+                                                  "(one for tables of 268 M rows and more): the tail of one launch under the scan tiles of the next")
+        except Exception as e:                                   # noqa: BLE001
+            log(f"engine-level leg failed: {e!r}")
+            result["engine_level"] = {"error": repr(e)}
+            result["config"]["level"] = "shim"
+    else:
+        result["config"]["level"] = "shim"
 
     # side measurements must never cost the headline line
     if rank == 0 and world == 1 and not args.no_extras:
@@ -483,13 +541,43 @@ def main():
 
 RING = 6                       # result slots in flight (the exchange holds two queries' payload back: needs >= 5)
 
-# the kernel instantiation each bench query dispatches to (rocprofv3 kernel names in profiles/)
-K_NAMES = {("S1", "ids"): "eval_chain_kernel<MODE_IDS, W0=2, W1=1, W2=0, S=1, NT, VC=false>",
-           ("S1", "count"): "eval_chain_kernel<MODE_COUNT, W0=2, W1=1, W2=0, S=1, NT, VC=false>",
-           ("Q_A", "ids"): "eval_chain_kernel<MODE_IDS, W0=4, W1=0, W2=0, S=1, NT, VC=true>",
-           ("Q_A", "count"): "eval_chain_kernel<MODE_COUNT, W0=4, W1=0, W2=0, S=1, NT, VC=true>",
-           ("Q_B", "ids"): "eval_chain_kernel<MODE_IDS, W0=4, W1=1, W2=0, S=1, NT, VC=false>",
-           ("Q_B", "count"): "eval_chain_kernel<MODE_COUNT, W0=4, W1=1, W2=0, S=1, NT, VC=false>"}
+def engine_leg(pq, chain, rows, seed, steps, warmup, count_mode, copies, threads, in_flight, log):
+    """The same stream of queries ONE LEVEL UP: through the engine API that replaces the reference's
+    (include/executeEngine-hip.h).  `copies` engines over the same seeded synthetic table (device-resident columns, no
+    host rows: initializeEngineSyntheticHIP), queries issued as asynchronous tickets on the engines' lanes by a C loop
+    (host/engineBench.c: hipEngineBench) -- no torch, no Python in the timed region; the results stay on the device."""
+    L = pq.lib()
+    engines = [pq.HipEngine.synthetic(rows, seed=seed) for _ in range(copies)]
+    try:
+        arr = (C.POINTER(pq.EngineS) * copies)(*[e.e for e in engines])
+        wl = pq.WhereList(chain)
+        for e in engines:
+            L.hipEngineKernelTiming(e.e, 1)
+        res = pq.BenchResult()
+        rc = L.hipEngineBench(arr, copies, wl.ptr, 1 if count_mode else 0, threads, in_flight, warmup, steps, C.byref(res))
+        if rc != 0:
+            raise pq.PqpsError("hipEngineBench: a query failed")
+        kern_ms, launches = 0.0, 0
+        for e in engines:
+            ev, tot, k = C.c_double(), C.c_double(), C.c_int()
+            if L.hipEngineKernelTime(e.e, C.byref(ev), C.byref(tot), C.byref(k)) == 0:
+                kern_ms += tot.value
+                launches += k.value
+        want = engines[0].count(chain)
+        assert res.matches == want and res.mismatches == 0, (res.matches, want, res.mismatches)
+        per_q = res.seconds / res.queries
+        out = {"value": rows * res.queries / res.seconds, "unit": "rows/s", "ms_per_query": per_q * 1e3, "queries": res.queries,
+               "threads": threads, "tickets_in_flight_per_thread": in_flight, "engines_alternated": copies, "matches": res.matches,
+               "host_issue_us_per_query": res.issue_seconds / res.queries * 1e6, "host_await_us_per_query": res.await_seconds / res.queries * 1e6,
+               "in_stream_kernel_ms": kern_ms / max(launches, 1), "launches_timed": launches,
+               "api": "initializeEngineSyntheticHIP + executeQuery%sAsyncHIP / awaitQueryHIP / releaseQueryHIP (host/engineBench.c)" % ("Count" if count_mode else "Select")}
+        log(f"engine level: {per_q * 1e6:.1f} us/query, {out['value'] / 1e12:.3f} T rows/s ({threads} thread(s) x {in_flight} tickets, {copies} engines); "
+            f"host {out['host_issue_us_per_query']:.1f} us issuing + {out['host_await_us_per_query']:.1f} us awaiting per query; "
+            f"launch in the stream {out['in_stream_kernel_ms'] * 1e3:.1f} us")
+        return out
+    finally:
+        for e in engines:
+            e.close()
 
 
 def pmc_traffic(query, rows):

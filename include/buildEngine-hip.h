@@ -56,6 +56,8 @@ struct hipLane {
     uint32_t *ids_dev;                           /* row numbers of the result, capacity_ids u32                 */
     uint64_t capacity_ids;
     uint64_t *count_dev;                         /* 8 x u64: count, spare, range[2], flag-pass count, spare ... */
+    volatile uint64_t *count_host;               /* the same words as the host sees them (pinned, mapped): read after the
+                                                    query's completion event, no download; NULL: count_dev is device memory */
     pqps_ctx *copy;                              /* context (stream) for this lane's downloads / gathers; NULL: the table's */
     uint32_t *merged_dev;                        /* shard 0 only, several shards: the gathered list of all shards */
     uint64_t merged_cap;

@@ -153,6 +153,13 @@ struct hipQueryTicket *executeQueryCountAsyncHIP(struct engineS *engine, struct 
 long long awaitQueryHIP(struct hipQueryTicket *ticket, struct hipDeviceResult *result /* may be NULL */);
 void releaseQueryHIP(struct hipQueryTicket *ticket);
 
+/* Device time of the engine's queries AS THEY RUN on the lanes (several in flight): the recorders of the shards' query
+ * streams (pqps_qstream_set_timing), events on the dispatch packets.  hipEngineKernelTime sums over the launches
+ * recorded since the last call: scan_ms = the filter launches alone, query_ms = whole queries (COUNT: + the
+ * one-workgroup reduction).  Up to 4096 launches per lane between two calls. */
+int hipEngineKernelTiming(struct engineS *engine, int enable);
+int hipEngineKernelTime(struct engineS *engine, double *scan_ms, double *query_ms, int *launches);
+
 /* Number of device shards the engine's table is split into (1 unless PQPS_DEVICES names several devices);
  * `rows` (may be NULL, room for that many entries) receives the rows each shard holds. */
 int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity);

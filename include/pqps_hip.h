@@ -128,6 +128,11 @@ int  pqps_device_info(pqps_ctx *ctx, char *name64, int *compute_units, uint64_t 
 /* Plain device memory helpers so a C host needs no HIP headers. */
 int  pqps_malloc(pqps_ctx *ctx, size_t bytes, void **dptr);
 int  pqps_free(pqps_ctx *ctx, void *dptr);
+/* Pinned host memory that the device addresses as well (zeroed): a kernel's few result words -- a match count --
+ * written there are on the host when the query's completion event has fired, no download call (~20 us of host
+ * time each) in between. */
+int  pqps_malloc_mapped(pqps_ctx *ctx, size_t bytes, void **host_ptr, void **dev_ptr);
+int  pqps_free_mapped(pqps_ctx *ctx, void *host_ptr);
 int  pqps_memset(pqps_ctx *ctx, void *dptr, int value, size_t bytes, void *stream);
 int  pqps_upload(pqps_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int  pqps_download(pqps_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);

@@ -17,11 +17,13 @@ The directory name contains '-', so import it with::
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 import subprocess
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libpqps_hip.so"
+# (PQPS_LIB: a development build of the same library, e.g. -DPQPS_DEV_SHAPES / -DPQPS_STAMPS, for tuning runs)
+LIB_PATH = pathlib.Path(os.environ.get("PQPS_LIB") or (PKG_DIR / "libpqps_hip.so"))
 
 MAX_COLUMNS = 12
 MAX_LEAVES = 32
@@ -104,6 +106,12 @@ class DeviceResult(C.Structure):
     """struct hipDeviceResult (include/executeEngine-hip.h)."""
     _fields_ = [("count", C.c_longlong), ("ids_dev", C.c_void_p), ("device", C.c_int), ("n_shards", C.c_int),
                 ("shard_count", C.c_ulonglong * 16)]
+
+
+class BenchResult(C.Structure):
+    """struct hipBenchResult (include/engineBench.h)."""
+    _fields_ = [("seconds", C.c_double), ("queries", C.c_longlong), ("matches", C.c_longlong), ("mismatches", C.c_longlong),
+                ("issue_seconds", C.c_double), ("await_seconds", C.c_double)]
 
 
 class EngineS(C.Structure):
@@ -324,6 +332,11 @@ def lib():
     L.awaitQueryHIP.argtypes = [vp, C.POINTER(DeviceResult)]
     L.releaseQueryHIP.argtypes = [vp]
     L.releaseQueryHIP.restype = None
+    L.hipEngineBench.argtypes = [C.POINTER(E), C.c_int, W, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BenchResult)]
+    L.hipEngineKernelTiming.argtypes = [E, C.c_int]
+    L.hipEngineKernelTime.argtypes = [E, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pqps_malloc_mapped.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.pqps_free_mapped.argtypes = [vp, vp]
     L.destroyEngineHIP.argtypes = [E]
     L.destroyEngineHIP.restype = None
     L.executeQuerySelectHIP.restype = C.POINTER(ResultSet)

@@ -76,6 +76,7 @@ struct EvalArgs {
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
     uint32_t grid_groups;            // gather: groups the grid was sized for (a wider range: the workgroups loop)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
+    uint32_t tune;                   // A/B switches of tuning runs (PQPS_TUNE): bit 0 = no second look ahead of early expander waves
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
     uint32_t n_cols;
@@ -102,7 +103,9 @@ struct EvalArgs {
 #define PQPS_STAMP_GROUP_MAX(a, g, k) do { if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&(a).stamps[4 + (g) * 8 + (k)], (unsigned long long)wall_clock64()); } while (0)
 #define PQPS_STAMP_VALUE(a, g, k, v) do { if ((threadIdx.x & 63) == 0) (a).stamps[4 + (g) * 8 + (k)] = (v); } while (0)
 #define PQPS_STAMP_TILE(a, t) do { if (threadIdx.x == 0) (a).stamps[4 + (a).stamp_groups * 8 + (t)] = wall_clock64(); } while (0)
+#define PQPS_STAMP_START(a) do { if (blockIdx.x == 0 && threadIdx.x == 0) (a).stamps[3] = wall_clock64(); } while (0)
 #else
+#define PQPS_STAMP_START(a) do { } while (0)
 #define PQPS_STAMP_GROUP(a, g, k) do { } while (0)
 #define PQPS_STAMP_GROUP_MAX(a, g, k) do { } while (0)
 #define PQPS_STAMP_VALUE(a, g, k, v) do { } while (0)
@@ -1104,16 +1107,12 @@ __device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedS
 // will expand it alone) and at most 16 non-empty steps gets those steps' slots requested in the packed order the
 // sparse branch of expand_range uses (slot k = the k-th non-empty step) -> returns 2 << 16 and the steps in `mask`;
 // otherwise the leader's own quarter as in prefetch_own_steps.
-__device__ __forceinline__ uint32_t prefetch_as_leader(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
-                                                       uint32_t park, uint64_t &mask) {
+// (`c`: lane l holds the count word of step l of the group, all 64 known to carry this query's epoch)
+__device__ __forceinline__ uint32_t leader_prefetch_with(const EvalArgs &a, FusedShared &sh, uint64_t g, uint32_t lane, uint32_t park,
+                                                         uint32_t c, uint64_t &mask) {
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
     mask = 0;
-    const uint64_t step = g * kGroupSteps + lane;
-    uint32_t c = a.epoch << kEpochShift;
-    if (step < ex.steps) c = ld_sc1(a.counts + step);
-    if (!__all((c >> kEpochShift) == a.epoch)) return 0u;            // uniform
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint64_t nonempty = __ballot((c & kCountMask) != 0);
     const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
     if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
@@ -1132,6 +1131,23 @@ __device__ __forceinline__ uint32_t prefetch_as_leader(const EvalArgs &a, FusedS
     }
     return bits | (1u << 16);
 }
+
+__device__ __forceinline__ uint32_t prefetch_as_leader(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
+                                                       uint32_t park, uint64_t &mask) {
+    mask = 0;
+    const uint64_t step = g * kGroupSteps + lane;
+    uint32_t c = a.epoch << kEpochShift;
+    if (step < ex.steps) c = ld_sc1(a.counts + step);
+    if (!__all((c >> kEpochShift) == a.epoch)) return 0u;            // uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return leader_prefetch_with(a, sh, g, lane, park, c, mask);
+}
+
+// What a leader that was early carries through its wait: the slots of its group are requested the moment its count words
+// turn out complete (settle_group), not after the sums in front have arrived as well -- for the groups of the last
+// wavefront of tiles, whose count words are never there at the first look, that is one memory latency (1 - 1.5 us) off
+// the end of the launch.
+struct LeaderPrefetch { FusedShared *sh; uint32_t park; uint32_t pre; uint64_t mask; };
 
 // The calling wave turns the match words of steps [c0, c1) of group g (both multiples of 16) into row IDs
 // (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
@@ -1234,7 +1250,7 @@ constexpr int kNearGroups = 6;     // supergroups in front whose group sums are 
 
 template <int NEAR>
 __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
-                                             uint32_t &cw, uint64_t &psum, bool final_word = false) {
+                                             uint32_t &cw, uint64_t &psum, bool final_word = false, LeaderPrefetch *lp = nullptr) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
     uint64_t own_super = 0;
     uint32_t left = 3u;
@@ -1257,6 +1273,10 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
             const uint32_t sum = wave_sum_u32(cw & kCountMask);
             if (lane == 0) st_sc1(a.gsum + g, tag | (uint64_t)sum);
             sum_out = true;
+            if (lp && lp->pre == 0u && !(a.tune & 1u)) {            // uniform: the look ahead at the start came too early
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                lp->pre = leader_prefetch_with(a, *lp->sh, g, lane, lp->park, g * kGroupSteps + lane < ex.steps ? cw : 0u, lp->mask);
+            }
         }
         if (left == 0 || spins >= limit || (long_wait && wall_clock64() > deadline)) break;
         __builtin_amdgcn_s_sleep(16);
@@ -1378,7 +1398,13 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
     uint32_t pre = 0;
     uint64_t pre_mask = 0;
     if constexpr (!GATHER) {                                        // (a gather workgroup's waves take 4 steps each)
-        if (shared) pre = leader ? prefetch_as_leader(a, sh, ex, g, lane, wave, pre_mask) : prefetch_own_steps(a, sh, ex, g, lane, c0, wave);
+        if (shared) {
+            pre = leader ? prefetch_as_leader(a, sh, ex, g, lane, wave, pre_mask) : prefetch_own_steps(a, sh, ex, g, lane, c0, wave);
+            // a wave of the last wavefront's groups is early: it has nothing else to do until its leader has settled the
+            // group (which cannot be before these count words exist), so it looks again a few times
+            if (!leader && !(a.tune & 1u))
+                for (uint32_t tries = 0; pre == 0u && tries < 12u; tries++) { __builtin_amdgcn_s_sleep(24); pre = prefetch_own_steps(a, sh, ex, g, lane, c0, wave); }
+        }
     }
     if (leader) {
         uint32_t cw = 0;
@@ -1390,7 +1416,10 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
         __builtin_amdgcn_s_setprio(3);
         // (gather: the whole grid is resident at once, so a wait can only fail if a tile never ran -- no second
         // chance through the recovery pass there, the wait is long and its failure sets the status word)
-        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, psum, GATHER);
+        LeaderPrefetch lp{&sh, wave, pre, pre_mask};
+        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, psum, GATHER, (!GATHER && shared) ? &lp : nullptr);
+        pre = lp.pre;
+        pre_mask = lp.mask;
         __builtin_amdgcn_s_setprio(0);
         PQPS_STAMP_GROUP(a, g, 2);
         if constexpr (!GATHER) ticket = ticket_draw(a, g, lane);    // past its wait (a group given up is on record by now)
@@ -1605,6 +1634,52 @@ __device__ __forceinline__ void eval_col(const EvalArgs &a, int slot, const RawC
     }
 }
 
+// ---- chain predicates on the VECTOR unit (kernel variant EV = 2) ---------------------------------------------
+// t[r] holds bit r in the lanes whose row r still satisfies every leaf seen so far; a leaf clears it where the row
+// fails (one compare + one select per row and leaf, no scalar instruction).  The ballot path costs ~50 scalar
+// instructions per leaf and step, and a CU has ONE scalar unit for its four SIMDs (rocprofv3 on S1 at 100 M rows: 227
+// SALU + 18 SMEM per 3 KB step, the scalar unit 80 % busy).  A kernel variant of its own: as a run-time branch next to
+// the ballot path it cost the other path its registers (85 - 93 VGPRs instead of 55 - 63 in the COUNT kernels).
+template <typename T>
+__device__ __forceinline__ void valu_leaf(const T (&v)[16], T lo, T span, bool want, uint32_t (&t)[16]) {
+    // `want`: the raw window hit this leaf needs; the six branches are wave-uniform
+    if (span == 0) {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = v[r] == lo ? t[r] : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = v[r] != lo ? t[r] : 0u;
+        }
+    } else if (lo == 0) {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = v[r] <= span ? t[r] : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = v[r] > span ? t[r] : 0u;
+        }
+    } else {
+        if (want) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = (T)(v[r] - lo) <= span ? t[r] : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = (T)(v[r] - lo) > span ? t[r] : 0u;
+        }
+    }
+}
+
+template <int W, int RPL, int U>
+__device__ __forceinline__ void eval_col_valu(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&t)[16]) {
+    static_assert(W <= 4, "the vector-unit chain path is for columns of up to 4 bytes");
+    const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
+    uint32_t v[16];
+    unpack32(raw, v, std::make_integer_sequence<int, 16>{});
+    for (uint32_t k = kb; k < ke; k++)                              // uniform
+        valu_leaf<uint32_t>(v, (uint32_t)a.lo[k], (uint32_t)a.span[k], ((a.chain_want >> k) & 1u) != 0, t);
+}
+
 constexpr int log2i(int x) { return x <= 1 ? 0 : 1 + log2i(x / 2); }
 
 // All raw registers of one step for the (W0, W1, W2) shape.
@@ -1664,9 +1739,11 @@ struct RawStep {
     // measured too: no gain -- with 3+ bytes per row the scalar unit is not what limits the scan.)
     // One step of a chain predicate: ID output -> the step's match count and the lanes' match bits;
     // COUNT -> cnt (ballot path) or lane_total (vector-unit path, summed once per wave at the end).
-    template <int MODE, bool VC>
+    // EV 0: ballots into SGPR planes (any chain); EV 1: ONE comparison on ONE column on the vector unit; EV 2: a chain over
+    // narrow columns on the vector unit (valu_leaf).
+    template <int MODE, int EV>
     __device__ __forceinline__ void eval_chain_step(const EvalArgs &a, uint32_t &cnt, uint32_t &mbits, uint32_t &lane_total) const {
-        if constexpr (VC) {
+        if constexpr (EV == 1) {
             static_assert(W1 == 0 && W2 == 0, "one column");
             uint32_t m = 0;
             if constexpr (W0 == 8) {
@@ -1681,6 +1758,25 @@ struct RawStep {
             if (MODE == MODE_IDS) {
                 cnt = wave_sum_u32(__popc(m));
                 mbits = m;
+            }
+        } else if constexpr (EV == 2) {
+            static_assert(W0 <= 4, "narrow columns");
+            uint32_t t[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) t[r] = 1u << r;
+            eval_col_valu<W0, RPL, U>(a, 0, r0, t);
+            if constexpr (W1 != 0) eval_col_valu<W1, RPL, U>(a, 1, r1, t);
+            if constexpr (W2 != 0) eval_col_valu<W2, RPL, U>(a, 2, r2, t);
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) m |= t[r];
+            if (a.chain == 2) m ^= 0xFFFFu;                         // OR form: NOT of the AND
+            if (MODE == MODE_IDS) {
+                // most steps of a sparse answer have no match: one compare + one scalar test instead of a wave reduction
+                cnt = __ballot(m != 0) ? wave_sum_u32(__popc(m)) : 0u;
+                mbits = m;
+            } else {
+                lane_total += __popc(m);
             }
         } else {
             eval_chain_half<MODE, 0>(a, cnt, mbits);
@@ -1771,8 +1867,11 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
 // 2 bytes per row on, 1 is best (u16+u8: 0.83 / 0.82 against 0.80 / 0.82 with 2 and 0.77 / 0.80 with 4).
 constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 2 : 1; }
 
-template <int MODE, int W0, int W1, int W2, int S, bool NT, bool VC>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_kernel(const EvalArgs a) {
+#ifndef PQPS_CHAIN_WGS
+#define PQPS_CHAIN_WGS 8
+#endif
+template <int MODE, int W0, int W1, int W2, int S, bool NT, int EV>
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void eval_chain_kernel(const EvalArgs a) {
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
     PQPS_HOIST_KERNARGS(a);
@@ -1784,6 +1883,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves * S;                          // a tile = S adjacent steps per wave
         __shared__ FusedShared sh;
+        PQPS_STAMP_START(a);
         zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
@@ -1800,7 +1900,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
             const uint64_t step = step0 + (uint64_t)i;
             uint32_t cnt = 0, mbits = 0, lane_total = 0;
             if (step < ex.steps) {
-                A[i].template eval_chain_step<MODE, VC>(a, cnt, mbits, lane_total);
+                A[i].template eval_chain_step<MODE, EV>(a, cnt, mbits, lane_total);
                 if (step >= full_steps) {                       // the partial last step
                     mbits &= rows_below<RPL>(step * kStepRows, n_rows, lane);
                     cnt = wave_sum_u32(__popc(mbits));
@@ -1831,14 +1931,14 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? 8 : 1) void eval_chain_k
                 const uint64_t step = step0 + (uint64_t)i;
                 if (step >= full_steps) break;
                 uint32_t cnt = 0, mbits = 0;
-                A[i].template eval_chain_step<MODE, VC>(a, cnt, mbits, lane_total);
+                A[i].template eval_chain_step<MODE, EV>(a, cnt, mbits, lane_total);
                 wave_total += cnt;
             }
         }
         if ((n_rows % kStepRows) != 0 && wave == full_steps % n_waves) {      // the partial last step: match bits, trimmed
             uint32_t cnt = 0, mbits = 0, unused = 0;
             A[0].template load<NT>(a, full_steps * kStepRows + lane_off);
-            A[0].template eval_chain_step<MODE_IDS, VC>(a, cnt, mbits, unused);
+            A[0].template eval_chain_step<MODE_IDS, EV>(a, cnt, mbits, unused);
             wave_total += wave_sum_u32(__popc(mbits & rows_below<RPL>(full_steps * kStepRows, n_rows, lane)));
         }
         wave_total += wave_sum_u32(lane_total);

@@ -474,18 +474,32 @@ typedef void (*eval_fn)(const EvalArgs);
     X(4,4,4) X(4,4,2) X(4,4,1) X(4,2,2) X(4,2,1) X(4,1,1) X(2,2,2) X(2,2,1) X(2,1,1) X(1,1,1)
 #endif
 
-// chain kernels exist with 1 step per iteration and (narrow shapes) with several
-// the vector-unit variant (VC) exists for the single-column shapes only
+// chain kernels exist with 1 step per iteration and (narrow shapes) with several, and in three evaluator variants:
+// EV 0 ballots (every shape), EV 1 one comparison on one column on the vector unit (single-column shapes), EV 2 a chain
+// on the vector unit (shapes of up to 8 bytes per row whose widest column has 4)
+constexpr uint64_t kInterleaveFromGroups = 4096;                    // from this many groups (268 M rows) on the expanders run among the scan tiles, see expand_lag()
+constexpr bool valu_chain_shape(int a, int b, int c) { return a <= 4 && a + b + c <= 8; }
+// ... and where it is the default.  A/B runs on one box (us per launch, ballots / vector unit): S1 = (2,1,0) as ID list at
+// 100 M rows 59.4 / 57.4, at 1 G rows 496 / 496, as COUNT(*) at 1 G rows 438 / 468; Q_B = (4,1,0) as ID list 103 / 113 (its
+// tile path spills at 64 VGPRs), at 1 G rows 901 / 959.  So: the u16 + u8 shape, ID output, below the size from which the
+// expanders run among the tiles.
+inline bool valu_chain_default(uint32_t w0, uint32_t w1, uint32_t w2, int mode, uint64_t n_rows) {
+    return mode == MODE_IDS && w0 == 2 && w1 == 1 && w2 == 0 && n_rows < kInterleaveFromGroups * (uint64_t)kGroupSteps * kStepRows;
+}
+
 template <int MODE, int A, int B, int C, int S, bool NT>
-eval_fn chain_variant(bool vc) {
+eval_fn chain_variant(int ev) {
     if constexpr (B == 0 && C == 0) {
-        if (vc) return eval_chain_kernel<MODE, A, B, C, S, NT, true>;
+        if (ev == 1) return eval_chain_kernel<MODE, A, B, C, S, NT, 1>;
     }
-    return eval_chain_kernel<MODE, A, B, C, S, NT, false>;
+    if constexpr (valu_chain_shape(A, B, C)) {
+        if (ev == 2) return eval_chain_kernel<MODE, A, B, C, S, NT, 2>;
+    }
+    return eval_chain_kernel<MODE, A, B, C, S, NT, 0>;
 }
 
 template <int MODE, bool NT>
-eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool vc) {
+eval_fn find_spec_nt(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, int vc) {
 #define X(A, B, C) if (w0 == A && w1 == B && w2 == C) return !chain ? eval_spec_kernel<MODE, A, B, C, NT> \
         : (multi_step ? chain_variant<MODE, A, B, C, chain_steps(A, B, C), NT>(vc) : chain_variant<MODE, A, B, C, 1, NT>(vc));
     PQPS_FOR_EACH_SHAPE(X)
@@ -510,7 +524,7 @@ void set_streaming(EvalArgs &a, const pqps_column *cols, uint32_t n_cols, uint64
 }
 
 template <int MODE>
-eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool nt, bool vc) {
+eval_fn find_spec(uint32_t w0, uint32_t w1, uint32_t w2, bool chain, bool multi_step, bool nt, int vc) {
     return nt ? find_spec_nt<MODE, true>(w0, w1, w2, chain, multi_step, vc) : find_spec_nt<MODE, false>(w0, w1, w2, chain, multi_step, vc);
 }
 
@@ -523,15 +537,19 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
         // several steps per iteration only where chain_steps() says so (a lone 1-byte column)
         static const char *force = getenv("PQPS_CHAIN_MULTI");
         const bool multi = force ? atoi(force) != 0 : true;
-        // one comparison on one column: the vector-unit kernel variant (see RawStep::one_leaf)
-        const bool vc = a.chain != 0 && pred->n_leaves == 1 && n_cols == 1;
+        // one comparison on one column (EV 1), or -- where measured faster -- a chain over narrow columns (EV 2), on the
+        // vector unit: see RawStep::one_leaf / valu_leaf
+        static const char *valu_env = getenv("PQPS_VALU_CHAIN");                 // tuning runs: 0 / 1 = ballots / vector unit for every eligible chain
+        const bool one = pred->n_leaves == 1 && n_cols == 1;
+        const bool valu = valu_chain_shape((int)w0, (int)w1, (int)w2) && (valu_env ? atoi(valu_env) != 0 : valu_chain_default(w0, w1, w2, MODE, n_rows));
+        const int vc = a.chain == 0 ? 0 : (one ? 1 : (valu ? 2 : 0));
         a.valu_chain = vc ? 1u : 0u;
         if (eval_fn f = find_spec<MODE>(w0, w1, w2, a.chain != 0, multi, a.streaming != 0, vc)) {   // nullptr unless widths are non-increasing
             if (a.chain != 0 && multi) a.steps_per_iter = (uint32_t)chain_steps((int)w0, (int)w1, (int)w2);
             const char *mode = MODE == MODE_IDS ? "MODE_IDS" : MODE == MODE_COUNT ? "MODE_COUNT" : "MODE_FLAGS";
             if (a.chain != 0)
-                snprintf(g_kernel, sizeof g_kernel, "eval_chain_kernel<%s, W0=%u, W1=%u, W2=%u, S=%u, NT=%s, VC=%s>", mode, w0, w1, w2,
-                         a.steps_per_iter ? a.steps_per_iter : 1u, a.streaming ? "true" : "false", vc ? "true" : "false");
+                snprintf(g_kernel, sizeof g_kernel, "eval_chain_kernel<%s, W0=%u, W1=%u, W2=%u, S=%u, NT=%s, EV=%d>", mode, w0, w1, w2,
+                         a.steps_per_iter ? a.steps_per_iter : 1u, a.streaming ? "true" : "false", vc);
             else
                 snprintf(g_kernel, sizeof g_kernel, "eval_spec_kernel<%s, W0=%u, W1=%u, W2=%u, NT=%s>", mode, w0, w1, w2, a.streaming ? "true" : "false");
             return f;
@@ -588,7 +606,6 @@ uint32_t expand_sum_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
 // a pipeline of ~2 * base groups to drain at the end; expanders behind the last tile cost the scan nothing but
 // run after it.  Measured (S1 / Q_A / Q_B, whole query): at 100 M rows (1.5 k groups) all behind wins (56 / 86 /
 // 105 us against 58 / 96 / 126), at 300 M rows the two are level, at 1 G rows among the tiles wins by 7 - 10 %.
-constexpr uint64_t kInterleaveFromGroups = 4096;
 
 uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group, uint64_t groups) {
     static const char *env = getenv("PQPS_EXPAND_LAG");
@@ -674,6 +691,8 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
     if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
     a.spin_limit = expand_spin_limit();
+    static const uint32_t tune = [] { const char *e = getenv("PQPS_TUNE"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+    a.tune = tune;
     // gather: [tiles of `groups` groups][four expander workgroups per group]; scan: quads of tiles with their expander slot, then the trailing groups
     const uint64_t main_blocks = gather ? groups * tiles_per_group : ((groups + 3) / 4) * (4ull * tiles_per_group + 1);
     const uint64_t lag = gather ? 4 * groups : trailing_groups((uint32_t)groups, a.lag);
@@ -694,7 +713,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         (void)hipStreamSynchronize(s);
         uint64_t *host = (uint64_t *)malloc(words * 8);
         (void)hipMemcpy(host, buf, words * 8, hipMemcpyDeviceToHost);
-        host[0] = groups; host[1] = tpg; host[2] = lag; host[3] = 0;
+        host[0] = groups; host[1] = tpg; host[2] = lag;         // (host[3]: the device's stamp of the launch's first instruction)
         if (FILE *f = fopen(path, "wb")) { fwrite(host, 8, words, f); fclose(f); }
         free(host);
     } } stamp_dump{stamp_buf, want_words, groups, tiles_per_group, a.lag, s};
@@ -916,6 +935,26 @@ int pqps_malloc(pqps_ctx *ctx, size_t bytes, void **dptr) {
 int pqps_free(pqps_ctx *ctx, void *dptr) {
     if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
     if (dptr) HIP_TRY(hipFree(dptr));
+    return PQPS_OK;
+}
+
+int pqps_malloc_mapped(pqps_ctx *ctx, size_t bytes, void **host_ptr, void **dev_ptr) {
+    if (!ctx || !host_ptr || !dev_ptr) return fail(PQPS_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, bytes ? bytes : 64, hipHostMallocMapped);
+    if (e != hipSuccess) return fail(PQPS_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { (void)hipHostFree(h); return fail(PQPS_EHIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    memset(h, 0, bytes ? bytes : 64);
+    *host_ptr = h;
+    *dev_ptr = d;
+    return PQPS_OK;
+}
+
+int pqps_free_mapped(pqps_ctx *ctx, void *host_ptr) {
+    if (!ctx) return fail(PQPS_EINVAL, "ctx is NULL");
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
     return PQPS_OK;
 }
 

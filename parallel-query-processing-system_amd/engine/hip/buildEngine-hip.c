@@ -432,13 +432,20 @@ static void lane_alloc(struct hipTable *sh, struct hipLane *L, bool own_context)
     memset(L, 0, sizeof *L);
     L->capacity_ids = sh->capacity_rows;
     if (pqps_malloc(sh->ctx, L->capacity_ids * sizeof(uint32_t), (void **)&L->ids_dev) != PQPS_OK) hip_die("result allocation");
-    if (pqps_malloc(sh->ctx, 8 * sizeof(uint64_t), (void **)&L->count_dev) != PQPS_OK) hip_die("counter allocation");
-    if (own_context && pqps_ctx_create(pqps_ctx_device(sh->ctx), &L->copy) != PQPS_OK) hip_die("lane context");
+    if (own_context) {
+        /* a query lane: its count words live in pinned host memory the device writes to directly */
+        void *host = NULL, *dev = NULL;
+        if (pqps_malloc_mapped(sh->ctx, 8 * sizeof(uint64_t), &host, &dev) != PQPS_OK) hip_die("counter allocation");
+        L->count_host = host;
+        L->count_dev = dev;
+        if (pqps_ctx_create(pqps_ctx_device(sh->ctx), &L->copy) != PQPS_OK) hip_die("lane context");
+    } else if (pqps_malloc(sh->ctx, 8 * sizeof(uint64_t), (void **)&L->count_dev) != PQPS_OK) hip_die("counter allocation");
 }
 
 static void lane_free(struct hipTable *sh, struct hipLane *L) {
     if (L->ids_dev) pqps_free(sh->ctx, L->ids_dev);
-    if (L->count_dev) pqps_free(sh->ctx, L->count_dev);
+    if (L->count_host) pqps_free_mapped(sh->ctx, (void *)L->count_host);
+    else if (L->count_dev) pqps_free(sh->ctx, L->count_dev);
     if (L->merged_dev) pqps_free(sh->ctx, L->merged_dev);
     if (L->copy) pqps_ctx_destroy(L->copy);
     memset(L, 0, sizeof *L);

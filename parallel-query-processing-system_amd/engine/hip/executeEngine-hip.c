@@ -413,7 +413,8 @@ static int query_await(struct query *q) {
             struct hipTable *sh = hipTableShard(q->t, s);
             struct hipLane *L = query_lane(q, s);
             if (rc == 0) rc = wait_shard(q, s);
-            if (rc == 0 && pqps_download(lane_copy_ctx(q, s), &q->count[s], L->count_dev, sizeof(uint64_t), NULL) != PQPS_OK) rc = engine_error("count download");
+            if (rc == 0 && L->count_host) q->count[s] = L->count_host[0];         /* written by the launch itself, on the host with its completion event */
+            else if (rc == 0 && pqps_download(lane_copy_ctx(q, s), &q->count[s], L->count_dev, sizeof(uint64_t), NULL) != PQPS_OK) rc = engine_error("count download");
             if (rc == 0 && !q->count_only && q->count[s] > L->capacity_ids) {
                 rc = grow_lane_ids(sh, L, q->count[s]);
                 again = true;
@@ -1063,6 +1064,34 @@ bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const c
     const bool ok = makeIndexHIP(engine, attributeName, attributeType);
     hipTableUnlockExclusive(engine->record_block);
     return ok;
+}
+
+int hipEngineKernelTiming(struct engineS *engine, int enable) {
+    if (!engine || !engine->record_block) return -1;
+    struct hipTable *t = engine->record_block;
+    int rc = 0;
+    hipTableLockExclusive(t);                                       /* no query in flight while the recorders are switched */
+    for (int s = 0; s < hipTableShards(t) && rc == 0; s++)
+        if (hipTableShard(t, s)->qs && pqps_qstream_set_timing(hipTableShard(t, s)->qs, enable) != PQPS_OK) rc = engine_error("kernel timing");
+    hipTableUnlockExclusive(t);
+    return rc;
+}
+
+int hipEngineKernelTime(struct engineS *engine, double *scan_ms, double *query_ms, int *launches) {
+    if (!engine || !engine->record_block || !scan_ms || !query_ms || !launches) return -1;
+    struct hipTable *t = engine->record_block;
+    *scan_ms = 0.0; *query_ms = 0.0; *launches = 0;
+    int rc = 0;
+    hipTableLockExclusive(t);
+    for (int s = 0; s < hipTableShards(t) && rc == 0; s++) {
+        double e = 0.0, q = 0.0;
+        int k = 0;
+        if (!hipTableShard(t, s)->qs) continue;
+        if (pqps_qstream_kernel_time(hipTableShard(t, s)->qs, &e, &q, &k) != PQPS_OK) { rc = engine_error("kernel timing"); break; }
+        *scan_ms += e; *query_ms += q; *launches += k;
+    }
+    hipTableUnlockExclusive(t);
+    return rc;
 }
 
 int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity) {

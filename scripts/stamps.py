@@ -18,6 +18,9 @@ e = d[4:4 + groups * 8].reshape(groups, 8).astype(np.int64)
 t = d[4 + groups * 8:].astype(np.int64)
 tv = t[t > 0]
 t0 = min(tv.min(), e[:, 0][e[:, 0] > 0].min())
+if int(d[3]) > 0:                                                 # the launch's first instruction (block 0): times below are from there
+    print(f"first tile ended {(tv.min() - int(d[3])) / 100.0:.1f} us after the launch's first instruction")
+    t0 = int(d[3])
 us = lambda x: (x - t0) / 100.0                                   # wall_clock64: 100 MHz
 print(f"groups {groups} tiles/group {tpg} trailing {lag}; tiles end: first {us(tv.min()):.1f}, p50 {us(np.median(tv)):.1f}, "
       f"p99 {us(np.percentile(tv, 99)):.1f}, last {us(tv.max()):.1f} us")

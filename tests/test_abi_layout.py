@@ -133,14 +133,16 @@ def _declared_functions(header):
 def test_library_exports_every_declared_symbol():
     lib = q.pq.lib()
     headers = ["pqps_hip.h", "executeEngine-hip.h", "buildEngine-hip.h", "hipPredicate.h", "connectEngine.h",
-               "printHelper.h", "sql.h", "recordSchema.h", "executeEngine-serial.h"]
+               "printHelper.h", "sql.h", "recordSchema.h", "executeEngine-serial.h", "engineBench.h"]
     declared = set()
     for h in headers:
         declared |= _declared_functions(q.ROOT / "include" / h)
     assert {"pqps_filter_scan", "pqps_filter_gather", "pqps_filter_count", "pqps_filter_flags", "pqps_index_build",
             "pqps_index_probe", "executeQuerySelectHIP", "initializeEngineHIP", "destroyEngineHIP",
             "linearSearchRecords", "evaluateWhereClause", "tokenize", "parse_tokens", "run_test_query",
-            "printTable", "hipCompileWhere"} <= declared
+            "printTable", "hipCompileWhere", "initializeEngineSyntheticHIP", "initializeEngineColumnsHIP",
+            "executeQuerySelectAsyncHIP", "executeQueryCountAsyncHIP", "awaitQueryHIP", "releaseQueryHIP", "hipEngineBench",
+            "pqps_qstream_scan_slot", "pqps_qstream_wait", "pqps_copy_peer", "pqps_last_kernel"} <= declared
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
 

@@ -51,6 +51,13 @@ def test_recovery_pass_expands_everything_on_its_own():
     run_driver(dict(env, PQPS_EXPAND_LAG="100000"), "sizes", "300001", "5000001")      # ... and when all expanders trail the tiles
 
 
+def test_epoch_wrap_of_the_handoff_words():
+    """The hand-off words carry a 16-bit epoch; after 65535 ID queries on a scratch it starts over and the tagged arrays
+    are zeroed.  A stream of queries gets there every few seconds; here the epoch starts 5 queries before the wrap."""
+    run_driver({"PQPS_EPOCH_START": "65530"}, "wrap", "300001")
+    run_driver({"PQPS_EPOCH_START": "65533", "PQPS_EXPAND_LAG": "2", "PQPS_SUM_LAG": "1"}, "wrap", "1100001")      # expanders among the tiles
+
+
 def test_dense_answer_above_600m_rows():
     n = 640_000_003
     seed = 99

@@ -163,3 +163,27 @@ def test_absent_column_is_an_error():
     # ... but not when the leaf can never be evaluated
     pred, _ = pq.compile_where(spec, [("nonexistent", "=", "1"), "AND", ("timestamp", ">", "2026")])
     assert pred.n_leaves == 0 and pred.truth == 0
+
+
+def test_flag_attributes_from_callers_are_unknown_attributes():
+    """'\\x01<n>' names the flag buffer of pass n INSIDE the planner only (hipPredicate.c:node_column).  A list that comes in
+    through the engine API with such a name must compile like any unknown attribute -- constant false (serial:278-281) --
+    and never become an index into flag buffers that do not exist."""
+    spec = pq.synth_schema()
+    for name in ("\x010", "\x011", "\x017", "\x01-1"):
+        pred, ids = pq.compile_where(spec, [(name, "=", "1")])
+        assert pred.n_leaves == 0 and pred.truth == 0 and ids == []
+        plan = pq.compile_plan(spec, [("risk_level", ">", "3"), "OR", (name, "=", "1", 0x7F1A6)])     # even with the planner's mark
+        assert len(plan) == 1 and plan[0][0].n_leaves == 1 and all(i < pq.MAX_COLUMNS for i in plan[0][1])
+
+
+def test_single_valued_dictionary_column_is_folded():
+    """A string column with ONE value needs no device buffer: a comparison on it is decided when the WHERE is compiled."""
+    spec = pq.SchemaSpec().set_numeric("risk_level", 4).set_dict("raw_command", 0, [b"cmd"])
+    cases = [("=", "cmd", True), ("!=", "cmd", False), ("<", "cmd", False), ("<=", "cmd", True), (">", "cm", True), (">=", "cmd", True),
+             ("=", "other", False), ("!=", "other", True), ("<", "z", True), (">", "z", False)]
+    for op, lit, truth in cases:
+        pred, ids = pq.compile_where(spec, [("raw_command", op, lit)])
+        assert pred.n_leaves == 0 and pred.truth == (1 if truth else 0), (op, lit)
+        pred, ids = pq.compile_where(spec, [("raw_command", op, lit), "AND", ("risk_level", "=", "5")])
+        assert (pred.n_leaves, len(ids)) == ((1, 1) if truth else (0, 0)), (op, lit)

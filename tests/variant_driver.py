@@ -140,6 +140,65 @@ def sweep_shapes(ctx, n):
     print(f"shapes: {len(SHAPES)} shapes x 4 forms ok at n={n}", flush=True)
 
 
+def sweep_wrap(ctx, n):
+    """Scan, index gather and query-stream queries in turn, many times over: with PQPS_EPOCH_START=65530 every scratch
+    (the context's and both lanes') takes its epoch through 65535 and starts over at 1 (the tagged hand-off words are
+    zeroed, csrc/pqps_hip.hip:run_filter) while words of the epochs before are still lying around."""
+    L = pq.lib()
+    dev = pq.SyntheticTable(ctx, n, seed=0xC0FFEE)
+    host = q.HostSynth(n, seed=0xC0FFEE)
+    out = Out(ctx, n + 8)
+    names = ["S1", "Q_A", "dense", "Q_C", "none", "u8"]
+    want = {k: host.oracle_scan(QUERIES[k]) for k in names}
+    bound = {k: dev.bind(QUERIES[k]) for k in names}
+    # an index on risk_level for the gather launches
+    perm, keys, rng = ctx.malloc(4 * n), ctx.malloc(4 * n), ctx.malloc(64)
+    col = pq.column_array([(dev.ptr["risk_level"], 4)])
+    pq.check(L.pqps_index_build(ctx.h, col, n, 1, perm, keys, None), "index build")
+    order = q.host_index_order(host.arr["risk_level"])
+    full = {k: np.zeros(n, dtype=bool) for k in names}
+    for k in names:
+        full[k][want[k]] = True
+    qs = C.c_void_p()
+    pq.check(L.pqps_qstream_create(ctx.h, 3, C.byref(qs)), "qstream")
+    ring = [Out(ctx, n + 8) for _ in range(3)]
+    issued = []
+    for it in range(40):
+        k = names[it % len(names)]
+        pred, cols, nc, _ = bound[k]
+        # plain scan on the context
+        pq.check(L.pqps_filter_scan(ctx.h, cols, nc, n, 0, C.byref(pred), out.ids, out.cap, out.count, None), k)
+        kk, got = out.result()
+        if kk != len(want[k]) or not np.array_equal(got, want[k]):
+            sys.exit(f"DIFF scan: it={it} query={k}")
+        # index gather: rows with risk_level >= 4 in leaf order, re-filtered by the query
+        ctx.memset(out.count, 0, 8)
+        pq.check(L.pqps_index_probe(ctx.h, keys, 4, 1, n, 4, 0x7FFFFFFF, rng, None), "probe")
+        pq.check(L.pqps_filter_gather(ctx.h, cols, nc, perm, rng, n, 0, C.byref(pred), out.ids, out.cap, out.count, None), "gather")
+        kk, got = out.result()
+        cand = order[host.arr["risk_level"][order] >= 4]
+        exp = cand[full[k][cand]].astype(np.uint32)
+        if kk != len(exp) or not np.array_equal(got, exp):
+            sys.exit(f"DIFF gather: it={it} query={k}: {kk} vs {len(exp)}")
+        # the query stream: two lanes, each with a scratch (and an epoch) of its own
+        slot = ring[it % 3]
+        if len(issued) == 3:
+            k0, s0 = issued.pop(0)
+            pq.check(L.pqps_qstream_wait(qs, ring.index(s0)), "wait")
+            c = C.c_uint64()
+            ctx.download(C.byref(c), s0.count, 8)
+            a = np.zeros(max(c.value, 1), dtype=np.uint32)
+            if c.value:
+                ctx.download(a.ctypes.data, s0.ids, 4 * c.value)
+            if c.value != len(want[k0]) or not np.array_equal(a[:c.value], want[k0]):
+                sys.exit(f"DIFF qstream: it={it} query={k0}")
+        pq.check(L.pqps_qstream_scan_slot(qs, it % 3, cols, nc, n, 0, C.byref(pred), slot.ids, slot.cap, slot.count, None), "qstream scan")
+        issued.append((k, slot))
+    pq.check(L.pqps_qstream_sync(qs), "qstream sync")
+    pq.check(L.pqps_qstream_destroy(qs), "qstream destroy")
+    print(f"wrap: 40 rounds of scan + gather + query stream ok at n={n}", flush=True)
+
+
 def main():
     mode = sys.argv[1]
     ctx = pq.Context(0)
@@ -147,6 +206,8 @@ def main():
         sweep_sizes(ctx, [int(x) for x in sys.argv[2:]] or [1, 4097, 65_537, 300_001, (1 << 21) + 17])
     elif mode == "shapes":
         sweep_shapes(ctx, int(sys.argv[2]) if len(sys.argv) > 2 else 70_001)
+    elif mode == "wrap":
+        sweep_wrap(ctx, int(sys.argv[2]) if len(sys.argv) > 2 else 300_001)
     else:
         sys.exit("usage: variant_driver.py sizes|shapes ...")
     ctx.close()
