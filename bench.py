@@ -48,6 +48,9 @@ QUERIES = {
             "exit_code != 0 AND user_id >= 1500 OR risk_level = 5"),
     "Q_u8": ([("sudo_used", "=", "TRUE")], "sudo_used = TRUE"),
     "Q_u16": ([("user_name", "=", "student1030")], 'user_name = "student1030"'),
+    # dense answers: 13.5 % and 43 % of the rows
+    "Q_r2": ([("risk_level", ">", "2")], "risk_level > 2"),
+    "Q_r1": ([("risk_level", ">", "1")], "risk_level > 1"),
 }
 
 
