@@ -5,8 +5,9 @@
  * oracle/_ref/libqpeseq_ref.so.  It drives the reference's public API
  * (tokenize -> parse_tokens -> convert_conditions -> executeQuerySelectSerial
  * -> printTable, exactly the chain of connectEngine.c:125-233) and serialises
- * what comes back so tests/golden/make_golden.py can turn it into fixtures and
- * tests/test_oracle_vs_ref.py can compare live.
+ * what comes back so tests/golden/make_golden.py can turn it into fixtures
+ * (tests/test_oracle_golden.py then checks the oracle against them; bench.py's
+ * cpu_baseline leg times linearSearchRecords of this library).
  *
  * TEST INFRASTRUCTURE ONLY.  Not part of the product, not shipped.
  */
