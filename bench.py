@@ -783,10 +783,16 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
     ring = [(ids, cnt)] + [(torch.empty(n1b // 8, dtype=torch.int32, device=device), torch.zeros(2, dtype=torch.int64, device=device))
                            for _ in range(2)]
     ns = {"rows": n1b}
-    for name in ("S1", "Q_A", "Q_B"):
+    for name in ("S1", "Q_A", "Q_B", "Q_u8", "Q_u16", "Q_r2", "Q_r1"):
         chain, sql = QUERIES[name]
+        if name == "Q_r2":                                                  # dense answers (135 M and 430 M IDs): one buffer of n / 2 entries,
+            del ring, ids                                                   # no stream leg (one lane at this size: stream = single)
+            torch.cuda.empty_cache()
+            ids = torch.empty(n1b // 2, dtype=torch.int32, device=device)
+            ring = None
         for mode in ("ids", "count"):
-            r = time_query(pq, L, ctx, [big], chain, mode, n1b, 0, ids, cnt, sptr, torch, reps=10, stream=(qs, ring))
+            r = time_query(pq, L, ctx, [big], chain, mode, n1b, 0, ids, cnt, sptr, torch, reps=10,
+                           stream=(qs, ring) if ring is not None else None)
             r["query"] = sql
             ns[f"{name}_{mode}"] = r
             log(f"1 G rows {name:>4} {mode:>5}: {r['avg_query_ms'] * 1e3:7.1f} us  {r['rows_per_s'] / 1e12:5.2f} T rows/s  "

@@ -12,8 +12,9 @@
 //            widest predicate column is ONE fully coalesced global_load_dwordx4 per chunk and narrower
 //            ones dwordx2 / dword / ushort loads that are just as contiguous across the wave.  A leaf is
 //            the unsigned window test ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth
-//            table (<= 6 leaves) or a jump table.  Output per step: 16 match bits per lane (128 bytes,
-//            skipped when the step has no match); per tile ONE store of its steps' COUNT WORDS
+//            table (<= 6 leaves) or a jump table.  Output per step, skipped when the step has no match: a list of
+//            16-bit row numbers in the context's list area (store_list16), or -- few matches, 1-byte columns,
+//            gathers -- a 128-byte slot with a packed 10-bit list or 16 match bits per lane; per tile ONE store of its steps' COUNT WORDS
 //            (epoch << 16 | log2(RPL) << 11 | matches) by wave 0 after the tile's barrier.  The first two
 //            tiles of a group also do SUM DUTY for a group / supergroup `sum_lag` groups back (a hint).
 //  expand    turns the match bits of a GROUP (64 steps = 64 K rows) into ascending row IDs.  It needs the
@@ -56,6 +57,7 @@ struct EvalArgs {
     uint64_t n_rows;                 // scan: rows; gather: caller's upper bound (range is on the device)
     uint16_t *masks;                 // [steps][64] match bits of every lane
     uint32_t *counts;                // [steps]     epoch << 16 | log2(RPL) << 11 | matches
+    uint16_t *lists;                 // [steps][1024] row lists of the fuller steps (see store_list16), or nullptr: bit masks for those
     uint8_t *out_flags;              // MODE_FLAGS
     uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
     const uint32_t *cand;            // gather: candidate row numbers
@@ -76,6 +78,7 @@ struct EvalArgs {
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
     uint32_t grid_groups;            // gather: groups the grid was sized for (a wider range: the workgroups loop)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
+    uint16_t list16_min[2];          // a step with MORE matches than this leaves a 16-bit row list ([1]: widest predicate column 1 byte wide)
     uint32_t tune;                   // A/B switches of tuning runs (PQPS_TUNE): bit 0 = no second look ahead of early expander waves
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -783,10 +786,81 @@ __device__ __forceinline__ void store_list(const EvalArgs &a, uint32_t *stage32,
     if (lane < 16) st_sc1((uint64_t *)(a.masks + step * 64) + lane, ((const uint64_t *)stage32)[lane]);
 }
 
+// A step with more than a.list16_min matches (host: 8) leaves them as a list of another kind when the launch has a list
+// area (a.lists): 16-bit row numbers inside the step, ascending, at lists[step * 1024 ...] -- 2 bytes per match instead of
+// a 128-byte slot with a bit mask or a packed 10-bit list.  Turning a dense bit mask into IDs costs the expander ~400 vector instructions per step (64 rows at a time:
+// read the bits of the 64 rows into a scalar pair, rank, store) and the expanders behind the last tile have nothing
+// to hide them under: `risk_level > 1` (43 % of 100 M rows) took 225 us, 160 of them after the last tile.  The
+// scan tile's vector units idle while it waits for memory; it ranks its own matches (two wave scans for the chunks'
+// per-lane counts, one LDS store per match) and the expander is left with a copy: four list entries + first row of
+// the step -> four IDs per lane and store.
+// (`step_uses_list16` must agree between the tile that writes and the expander that reads: both see the count word.)
+__device__ __forceinline__ bool step_uses_list16(const EvalArgs &a, uint32_t cnt, uint32_t rpl_log2) {
+    return a.lists != nullptr && cnt > (uint32_t)a.list16_min[rpl_log2 >= 4u ? 1 : 0];
+}
+// the steps of a group that have a 128-byte slot to fetch (`cw` = a step's count word)
+__device__ __forceinline__ bool step_has_slot(const EvalArgs &a, uint32_t cw) {
+    const uint32_t cnt = cw & kCountMask;
+    return cnt != 0u && !step_uses_list16(a, cnt, (cw >> kRplShift) & 7u);
+}
+
+template <int RL>
+__device__ __forceinline__ void store_list16(const EvalArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t lane) {
+    constexpr uint32_t RPL = 1u << RL, CH = 16u >> RL;              // RL = 2, 3, 4: 4, 2, 1 chunks of 64 * RPL rows
+    static_assert(RL >= 2 && RL <= 4, "widest predicate column: 8 / 4, 2 or 1 bytes");
+    // rank of a lane's first match in each chunk: chunk by chunk, inside a chunk lane by lane (= ascending rows);
+    // two chunks share a wave scan as 16-bit fields (a chunk has at most 512 matches)
+    uint32_t at[CH];
+    if constexpr (CH == 1) {
+        const uint32_t per = (uint32_t)__popc(mbits);
+        at[0] = wave_incl_scan_u32(per) - per;
+    } else {
+        const uint32_t nib = (1u << RPL) - 1u;
+        const uint32_t per01 = (uint32_t)__popc(mbits & nib) | ((uint32_t)__popc((mbits >> RPL) & nib) << 16);
+        const uint32_t incl01 = wave_incl_scan_u32(per01);
+        const uint32_t tot01 = (uint32_t)__builtin_amdgcn_readlane((int)incl01, 63);
+        const uint32_t ex01 = incl01 - per01;
+        at[0] = ex01 & 0xFFFFu;
+        at[1] = (tot01 & 0xFFFFu) + (ex01 >> 16);
+        if constexpr (CH == 4) {
+            const uint32_t per23 = (uint32_t)__popc((mbits >> (2 * RPL)) & nib) | ((uint32_t)__popc((mbits >> (3 * RPL)) & nib) << 16);
+            const uint32_t incl23 = wave_incl_scan_u32(per23);
+            const uint32_t tot23 = (uint32_t)__builtin_amdgcn_readlane((int)incl23, 63);
+            const uint32_t ex23 = incl23 - per23, front = (tot01 & 0xFFFFu) + (tot01 >> 16);
+            at[2] = front + (ex23 & 0xFFFFu);
+            at[3] = front + (tot23 & 0xFFFFu) + (ex23 >> 16);
+        }
+    }
+    const uint32_t lane_rows = lane << RL;
+#pragma unroll
+    for (uint32_t c = 0; c < CH; c++) {                             // trip count of each loop: the fullest lane's matches in the chunk (<= RPL)
+        uint32_t m = (mbits >> (c * RPL)) & ((1u << RPL) - 1u);
+        uint16_t *out = stage + at[c];
+        const uint32_t row0 = (c << (6u + RL)) + lane_rows;
+        while (m) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            *out++ = (uint16_t)(row0 + j);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the same wave wrote the stage)
+    uint64_t *dst = (uint64_t *)(a.lists + step * kStepRows);
+#pragma unroll
+    for (uint32_t r = 0; r < 4; r++)                                // 256 entries per store instruction
+        if (r * 256u < cnt) {                                       // uniform
+            if (r * 256u + lane * 4u < cnt) st_sc1(dst + r * 64u + lane, ((const uint64_t *)stage)[r * 64u + lane]);
+        }
+}
+
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
-    if (cnt > list_limit(rpl_log2)) store_mask(a, step, mbits, lane);
+    if (step_uses_list16(a, cnt, rpl_log2)) {
+        uint16_t *stage = (uint16_t *)sh.stage[threadIdx.x >> 6];                  // 2 KB per wave: 1024 entries
+        if (rpl_log2 == 2u) store_list16<2>(a, stage, step, mbits, cnt, lane);      // uniform
+        else if (rpl_log2 == 3u) store_list16<3>(a, stage, step, mbits, cnt, lane);
+        else store_list16<4>(a, stage, step, mbits, cnt, lane);
+    } else if (cnt > list_limit(rpl_log2)) store_mask(a, step, mbits, lane);
     else if (cnt) store_list(a, (uint32_t *)&sh.mask[threadIdx.x >> 6][0][0], step, mbits, rpl_log2, lane);
     if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << kRplShift);
 }
@@ -960,9 +1034,100 @@ __device__ __forceinline__ void expand_block16(const EvalArgs &a, uint64_t begin
 }
 
 // `slot` = the step's 128 bytes as parked in LDS: a row list (count <= kListIds, see store_list) or 16 match bits per lane.
+// A step whose matches were left as 16-bit row numbers (store_list16): a copy.  Lane l of round q takes entries
+// 256 q + 4 l .. + 3 -- one 8-byte load, four adds, one 16-byte store (the output run of a step starts wherever the
+// matches in front of it end, so the store is only 4-byte aligned: global memory accesses may be).
+__device__ __forceinline__ void expand_step_list16(const EvalArgs &a, uint64_t step, uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    if (r.pending) ring_flush(a, ring, r, lane, r.pending);         // < 64 staged IDs from the steps before
+    const uint64_t *src = (const uint64_t *)(a.lists + step * kStepRows) + lane;
+    const uint32_t base = (uint32_t)(step * kStepRows) + a.id_base;
+    // entries that have a place in the caller's buffer (a result that does not fit is cut off, the count says so)
+    const uint64_t room = r.pos < a.out_cap ? a.out_cap - r.pos : 0ull;
+    const uint32_t lim = room < (uint64_t)count ? (uint32_t)room : count;
+    uint64_t w[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        w[q] = 0;
+        if (q * 256u + lane * 4u < lim) w[q] = ld_sc1(src + q * 64u);
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t e0 = q * 256u + lane * 4u;
+        if (q * 256u < lim) {                                       // uniform
+            const uint32_t lo = (uint32_t)w[q], hi = (uint32_t)(w[q] >> 32);
+            const uint32_t i0 = base + (lo & 0xFFFFu), i1 = base + (lo >> 16), i2 = base + (hi & 0xFFFFu), i3 = base + (hi >> 16);
+            uint32_t *o = a.out_ids + r.pos + e0;
+            if (e0 + 4u <= lim) {
+                u32x4_a4 v;
+                v.x = i0; v.y = i1; v.z = i2; v.w = i3;
+                *(u32x4_a4 *)o = v;
+            } else if (e0 < lim) {                                  // the list's last lane: 1 - 3 entries
+                o[0] = i0;
+                if (e0 + 1u < lim) o[1] = i1;
+                if (e0 + 2u < lim) o[2] = i2;
+            }
+        }
+    }
+    r.pos += count;
+}
+
+// The same for a BLOCK of four consecutive steps (`which`: bit i = step0 + i left a 16-bit list; `cnt[i]` / `off[i]`: its
+// matches and its first output slot).  One step at a time the copy is a chain of memory latencies -- 138 entries are
+// one 276-byte load per wave, and 16 steps per wave one after the other made the expansion of a 13 % answer take 23 us
+// per group at 3.5 TB/s of copy traffic.  Here the first 512 entries of all four steps are requested before any is
+// awaited (8 loads in flight per wave); fuller steps get a second round.
+__device__ __forceinline__ void expand_block_list16(const EvalArgs &a, uint64_t step0, uint32_t which, const uint32_t (&cnt)[4], const uint64_t (&off)[4], uint32_t lane) {
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    uint32_t lim[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint64_t room = off[i] < a.out_cap ? a.out_cap - off[i] : 0ull;
+        lim[i] = !((which >> i) & 1u) ? 0u : (room < (uint64_t)cnt[i] ? (uint32_t)room : cnt[i]);
+    }
+    auto put = [&](uint32_t i, uint32_t q, uint64_t w) {
+        const uint32_t e0 = q * 256u + lane * 4u;
+        const uint32_t base = (uint32_t)((step0 + i) * kStepRows) + a.id_base;
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        const uint32_t i0 = base + (lo & 0xFFFFu), i1 = base + (lo >> 16), i2 = base + (hi & 0xFFFFu), i3 = base + (hi >> 16);
+        uint32_t *o = a.out_ids + off[i] + e0;
+        if (e0 + 4u <= lim[i]) {
+            u32x4_a4 v;
+            v.x = i0; v.y = i1; v.z = i2; v.w = i3;
+            *(u32x4_a4 *)o = v;
+        } else if (e0 < lim[i]) {                                   // the list's last lane: 1 - 3 entries
+            o[0] = i0;
+            if (e0 + 1u < lim[i]) o[1] = i1;
+            if (e0 + 2u < lim[i]) o[2] = i2;
+        }
+    };
+#pragma unroll
+    for (uint32_t half = 0; half < 2; half++) {                     // entries [0, 512), then [512, 1024) of the steps that have them
+        if (half == 1 && lim[0] <= 512u && lim[1] <= 512u && lim[2] <= 512u && lim[3] <= 512u) break;     // uniform
+        uint64_t w[4][2];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+#pragma unroll
+            for (uint32_t q = 0; q < 2; q++) {
+                w[i][q] = 0;
+                const uint32_t qq = 2u * half + q;
+                if (qq * 256u + lane * 4u < lim[i]) w[i][q] = ld_sc1((const uint64_t *)(a.lists + (step0 + i) * kStepRows) + qq * 64u + lane);
+            }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+#pragma unroll
+            for (uint32_t q = 0; q < 2; q++) {
+                const uint32_t qq = 2u * half + q;
+                if (qq * 256u < lim[i]) put(i, qq, w[i][q]);         // uniform
+            }
+    }
+}
+
 template <bool GATHER>
 __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
+    if constexpr (!GATHER)
+        if (step_uses_list16(a, count, rpl_log2)) { expand_step_list16(a, step, count, lane, ring, r); return; }   // uniform
     if (count <= list_limit(rpl_log2)) {
 #pragma unroll 1
         for (uint32_t i0 = 0; i0 < count; i0 += 64) {               // uniform: one round, two for more than 64 entries
@@ -1094,7 +1259,7 @@ __device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedS
     if (lane < 16 && step < ex.steps) c = ld_sc1(a.counts + step);
     if (!__all((c >> kEpochShift) == a.epoch)) return 0u;            // uniform
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          // no instruction: the payload loads stay behind the look
-    const uint32_t bits = uniform_u32((uint32_t)__ballot(lane < 16 && (c & kCountMask) != 0) & 0xFFFFu);
+    const uint32_t bits = uniform_u32((uint32_t)__ballot(lane < 16 && step_has_slot(a, c)) & 0xFFFFu);
     const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + c0) * 64) + lane;
     for (uint32_t rest = bits; rest; rest &= rest - 1) {            // uniform
         const uint32_t k = (uint32_t)__builtin_ctz(rest);
@@ -1113,7 +1278,7 @@ __device__ __forceinline__ uint32_t leader_prefetch_with(const EvalArgs &a, Fuse
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
     mask = 0;
-    const uint64_t nonempty = __ballot((c & kCountMask) != 0);
+    const uint64_t nonempty = __ballot(step_has_slot(a, c));        // (a group that is its leader's alone has no step with a 16-bit list)
     const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
     if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
         uint32_t k = 0;
@@ -1163,6 +1328,7 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     const uint64_t span = (c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
     const uint64_t nonempty = __ballot(my_cnt != 0) & span;         // non-empty steps of the range (wave-uniform)
     if (!nonempty) return;
+    const uint64_t slotted = __ballot(step_has_slot(a, cw)) & span; // ... those with a 128-byte slot to fetch (the others left a 16-bit list)
     const uint32_t rpl_log2 = ((uint32_t)__builtin_amdgcn_readlane((int)cw, (int)__builtin_ctzll(nonempty)) >> kRplShift) & 7u;   // one per query
     uint32_t *ring = sh.stage[park];
     OutRing r;
@@ -1172,8 +1338,8 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
     // the prefetched words serve if they are exactly what this range needs (same 16 steps, same non-empty ones)
-    const bool have = (pre >> 16) == 1u && c1 == c0 + 16u && (uint32_t)(nonempty >> c0) == (pre & 0xFFFFu);    // uniform
-    const bool have_packed = (pre >> 16) == 2u && nonempty == pre_mask;     // the leader's look ahead for a group it expands alone
+    const bool have = (pre >> 16) == 1u && c1 == c0 + 16u && (uint32_t)(slotted >> c0) == (pre & 0xFFFFu);    // uniform
+    const bool have_packed = (pre >> 16) == 2u && slotted == pre_mask;      // the leader's look ahead for a group it expands alone
     // matches of the block of 4 steps a lane's step belongs to (DPP quad sums; used for 1-byte predicates)
     uint32_t quad = my_cnt + dpp_or_zero<0xb1>(my_cnt);
     quad += dpp_or_zero<0x4e>(quad);
@@ -1184,16 +1350,16 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
         const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
         uint32_t k = 0;
         if (!have && !have_packed)
-            for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
+            for (uint64_t rest = slotted; rest; rest &= rest - 1, k++) {      // uniform
                 const uint32_t st = (uint32_t)__builtin_ctzll(rest);
                 if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gm + (size_t)st * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler does not count LDS-DMA as a write to LDS)
         if (c0 == 0) PQPS_STAMP_GROUP(a, g, 5);
-        k = 0;
-        for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {
+        for (uint64_t rest = nonempty; rest; rest &= rest - 1) {
             const uint32_t st = (uint32_t)__builtin_ctzll(rest);
             const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
+            k = (uint32_t)__popcll(slotted & ((1ull << st) - 1ull));  // packed: slot k = the k-th step that has one
             expand_step<GATHER>(a, ex.begin, g * kGroupSteps + st, sh.mask[park][have ? st - c0 : k], rpl_log2, cwi & kCountMask, lane, ring, r);
         }
         if (r.pending) ring_flush(a, ring, r, lane, r.pending);
@@ -1204,13 +1370,14 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
     for (uint32_t w0 = c0; w0 < c1; w0 += kGroupSteps / kWaves) {   // 16 steps at a time
         const uint32_t bits = uniform_u32((uint32_t)(nonempty >> w0) & 0xFFFFu);
         if (!bits) continue;
+        const uint32_t fetch = uniform_u32((uint32_t)(slotted >> w0) & 0xFFFFu);
         // The match words of the window's non-empty steps go from memory straight into LDS (LDS-DMA: 128 bytes per
         // step by 32 lanes, no vector register in between), all requested before any is awaited: one memory
         // latency per window.  The slot of an empty step keeps whatever it held: nobody looks at it.
         {
             const uint32_t *gmask = (const uint32_t *)(a.masks + (g * kGroupSteps + w0) * 64) + lane;
             if (!(have && w0 == c0))                                // (prefetched: the words of this window are on their way already)
-                for (uint32_t rest = bits; rest; rest &= rest - 1) {    // uniform
+                for (uint32_t rest = fetch; rest; rest &= rest - 1) {   // uniform
                     const uint32_t k = (uint32_t)__builtin_ctz(rest);
                     if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
                 }
@@ -1222,13 +1389,30 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
             if (!nb) continue;
             const uint32_t sidx0 = w0 + 4 * bb;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
-            if (rpl_log2 == 4 && total <= kBlockIds) {              // uniform
+            uint32_t lb = 0;                                        // steps of the block that left 16-bit lists: copied together
+            if constexpr (!GATHER) lb = nb & ~((fetch >> (4 * bb)) & 0xFu);
+            if (rpl_log2 == 4 && total <= kBlockIds && lb == 0u) {  // uniform
                 expand_block16<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
                 continue;
+            }
+            if (lb) {
+                uint32_t cnt4[4];
+                uint64_t off4[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) {
+                    cnt4[i] = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i)) & kCountMask;
+                    off4[i] = readlane_u64(my_off, (int)(sidx0 + i));
+                }
+                expand_block_list16(a, g * kGroupSteps + sidx0, lb, cnt4, off4, lane);
             }
             for (uint32_t i = 0; i < 4; i++) {
                 if (!((nb >> i) & 1u)) continue;
                 const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i));
+                if ((lb >> i) & 1u) {                               // (done above; its IDs interrupt the run of the steps around it)
+                    if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+                    r.pos += cwi & kCountMask;
+                    continue;
+                }
                 expand_step<GATHER>(a, ex.begin, g * kGroupSteps + sidx0 + i, sh.mask[park][4 * bb + i], rpl_log2, cwi & kCountMask, lane, ring, r);
             }
         }

@@ -287,6 +287,9 @@ struct pqps_ctx {
     uint64_t scratch_steps;     // capacity in steps of 1024 rows
     uint16_t *masks;            // [steps][64] match words
     uint32_t *counts;           // [steps] step counts; all zero between queries
+    uint16_t *lists;            // [list_steps][1024] 16-bit row lists of the fuller steps (ID scans; allocated with the first one)
+    uint64_t list_steps;
+    bool lists_refused;         // the list area did not fit into device memory: bit masks for every step from then on
     // hand-off words of the ID-output launch (filter_kernels.hpp): tagged with the query's epoch, so nothing but
     // the two counters of ctl needs zeroing -- and those are a ping-pong pair, zeroed by the query before
     uint64_t *gsum, *ssum;      // [hand_groups], [hand_groups / 64 + 1]
@@ -319,8 +322,9 @@ hipStream_t pick_stream(pqps_ctx *ctx, void *stream) {
 }
 
 void free_scratch(pqps_ctx *ctx) {
-    void *all[] = {ctx->masks, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials};
+    void *all[] = {ctx->masks, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials, ctx->lists};
     for (void *p : all) if (p) (void)hipFree(p);
+    ctx->lists = nullptr; ctx->list_steps = 0;
     ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->scratch_steps = 0;
@@ -366,6 +370,25 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     ctx->epoch = first_epoch();
     ctx->needs_reset = false;
     return PQPS_OK;
+}
+
+// The list area of ID scans: 2 KB per step (2 bytes per row of the largest table scanned so far on this context), taken
+// when the first ID scan comes along.  If the device cannot spare it the scans go on with bit masks (slower for answers
+// of more than a tenth of the rows, same results).  PQPS_LIST16=0: never (tests, A/B runs).
+uint16_t *ensure_lists(pqps_ctx *ctx, uint64_t steps) {
+    static const bool enabled = [] { const char *e = getenv("PQPS_LIST16"); return !e || atoi(e) != 0; }();
+    if (!enabled || ctx->lists_refused) return nullptr;
+    if (ctx->lists && ctx->list_steps >= steps) return ctx->lists;
+    if (ctx->lists) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(ctx->lists); ctx->lists = nullptr; ctx->list_steps = 0; }
+    const uint64_t cap = steps + steps / 4 + 64;
+    if (hipMalloc((void **)&ctx->lists, cap * kStepRows * sizeof(uint16_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->lists = nullptr;
+        ctx->lists_refused = true;
+        return nullptr;
+    }
+    ctx->list_steps = cap;
+    return ctx->lists;
 }
 
 // Back to "never written" on the stream the next query runs on: after a failed launch (the ctl half it would have
@@ -680,6 +703,18 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.ctl = ctx->ctl + half * kCtlWords;
     a.zctl = ctx->ctl + (half ^ 1) * kCtlWords;
     a.base_slot = ctx->base_slot;
+    a.lists = gather ? nullptr : ensure_lists(ctx, steps);
+    {
+        // Measured at 100 M rows (S1 / Q_A / Q_B / risk_level > 2, us per query): from 103 matches on 58.7 / 91.7 / 108.6 / 91.7, from 33
+        // 57.8 / 90.6 / 104.6 / 91.8, from 9 58.3 / 88.8 / 104.4 / 91.5, every non-empty step 60.7 / 88.7 / 104.2 / 91.6: the 10-bit list
+        // inside the step's 128-byte slot stays for the steps of a sparse answer (their slots are fetched while the leader
+        // still waits for the sums in front).  1-byte columns: their tiles have no instruction slots to spare (a lone u8
+        // column with 7 % matches: 47.5 us with bit masks, 56 - 58 with lists).
+        static const uint32_t from = [] { const char *e = getenv("PQPS_LIST16_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 8u; }();
+        static const uint32_t from_u8 = [] { const char *e = getenv("PQPS_LIST16_MIN_U8"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; }();
+        a.list16_min[0] = (uint16_t)(from < 1024u ? from : 1024u);
+        a.list16_min[1] = (uint16_t)(from_u8 < 1024u ? from_u8 : 1024u);
+    }
     a.status = ctx->status_dev;
     a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
     a.id_base = id_base;
@@ -793,6 +828,7 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->scratch_steps = 0;
     ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
+    ctx->lists = nullptr; ctx->list_steps = 0; ctx->lists_refused = false;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
     ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset = false;
     ctx->sort_tmp = nullptr;

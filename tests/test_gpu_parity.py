@@ -539,6 +539,38 @@ def test_capacity_overflow_is_reported_not_written(ctx):
     dev.free()
 
 
+@pytest.mark.parametrize("cap", [1, 103, 1001, 1003, 4096, 70_001, 200_002])
+def test_a_result_buffer_that_is_too_small_is_filled_and_not_overrun(ctx, cap):
+    """Dense and sparse steps (row lists of both kinds, bit masks of a 1-byte column): the first `cap` IDs arrive, the
+    count is the true one, nothing behind the buffer's end is touched -- whatever lane and store the end falls into."""
+    n = 500_001
+    dev = pq.SyntheticTable(ctx, n, seed=5)
+    host = q.HostSynth(n, seed=5)
+    guard = 4096
+    buf = ctx.malloc(4 * (cap + guard))
+    cnt = ctx.malloc(64)
+    sentinel = np.full(cap + guard, 0xDEADBEEF, dtype=np.uint32)
+    for chain in ([("risk_level", ">", "1")], [("risk_level", ">", "2")], [("risk_level", ">", "3")], [("sudo_used", "=", "FALSE")],
+                  [("user_name", "!=", "student1030")], [("exit_code", "!=", "0"), "AND", ("user_id", ">=", "1500"), "OR", ("risk_level", "=", "5")]):
+        want = host.oracle_scan(chain)
+        if len(want) <= cap:
+            continue
+        ctx.upload(buf, sentinel.ctypes.data, sentinel.nbytes)
+        pred, cols, nc, _ = dev.bind(chain)
+        pq.check(pq.lib().pqps_filter_scan(ctx.h, cols, nc, n, 0, C.byref(pred), buf, cap, cnt, None))
+        ctx.sync()
+        k = C.c_uint64()
+        ctx.download(C.byref(k), cnt, 8)
+        got = np.zeros(cap + guard, dtype=np.uint32)
+        ctx.download(got.ctypes.data, buf, got.nbytes)
+        assert k.value == len(want), chain
+        assert np.array_equal(got[:cap], want[:cap]), chain
+        assert np.all(got[cap:] == 0xDEADBEEF), chain
+    ctx.free(buf)
+    ctx.free(cnt)
+    dev.free()
+
+
 # ---- engine level: golden vectors of the real reference -------------------------------
 def sha_rows(rows):
     h = hashlib.sha256()
