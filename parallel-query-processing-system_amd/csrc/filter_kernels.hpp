@@ -101,6 +101,21 @@ struct EvalArgs {
 #endif
 };
 
+// Device code reads the arguments where the launch put them: the kernel-argument segment (constant address space, scalar
+// loads).  The kernels take `EvalArgs` by value (that fixes the segment's layout) and bind this reference to its start; the
+// expander paths go through a pointer the compiler cannot see through (args_for_expanders), so that the ~25 fields only
+// they need are fetched after the role branch.  With the by-value parameter the compiler fetched everything at the top of
+// the kernel, in five dependent rounds of scalar loads with spills to vector-register lanes in between -- 157 instructions
+// and ~1 us before a scan tile had its first column load in flight (COUNT kernels: 61 instructions, one round), and a
+// one-shot tile lives 2.5 - 3.5 us.
+typedef const __attribute__((address_space(4))) EvalArgs CArgs;
+__device__ __forceinline__ CArgs &kernel_args() { return *(CArgs *)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ CArgs &args_for_expanders() {
+    CArgs *p = (CArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
 #ifdef PQPS_STAMPS
 #define PQPS_STAMP_GROUP(a, g, k) do { if ((threadIdx.x & 63) == 0) (a).stamps[4 + (g) * 8 + (k)] = wall_clock64(); } while (0)
 #define PQPS_STAMP_GROUP_MAX(a, g, k) do { if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long *)&(a).stamps[4 + (g) * 8 + (k)], (unsigned long long)wall_clock64()); } while (0)
@@ -178,7 +193,7 @@ __device__ __forceinline__ uint64_t load_one(const void *base, int wlog2, uint64
 
 // Window test of every leaf of one column on R values; sets bit k of idx[r].
 template <typename T, int R>
-__device__ __forceinline__ void apply_leaves(const EvalArgs &a, uint32_t kb, uint32_t ke,
+__device__ __forceinline__ void apply_leaves(CArgs &a, uint32_t kb, uint32_t ke,
                                              const T (&v)[R], uint32_t (&idx)[R]) {
     for (uint32_t k = kb; k < ke; k++) {                        // uniform; operands come in SGPRs
         const T lo = (T)a.lo[k], span = (T)a.span[k];
@@ -193,7 +208,7 @@ __device__ __forceinline__ void apply_leaves(const EvalArgs &a, uint32_t kb, uin
 
 // Boolean tree on the leaf bits of R rows -> R match bits (bit r).
 template <int R>
-__device__ __forceinline__ uint32_t combine_leaves(const EvalArgs &a, const uint32_t (&idx)[R]) {
+__device__ __forceinline__ uint32_t combine_leaves(CArgs &a, const uint32_t (&idx)[R]) {
     uint32_t m = 0;
     if (a.n_leaves <= PQPS_TT_LEAVES) {
         const uint64_t tt = a.truth;
@@ -243,7 +258,7 @@ __device__ __forceinline__ uint32_t leaf_mask(const T (&v)[R], T lo, T span) {
 struct LeafMasks { uint32_t m[PQPS_TT_LEAVES]; };
 
 template <typename T, int R>
-__device__ __forceinline__ void apply_leaves_masks(const EvalArgs &a, uint32_t kb, uint32_t ke,
+__device__ __forceinline__ void apply_leaves_masks(CArgs &a, uint32_t kb, uint32_t ke,
                                                    const T (&v)[R], LeafMasks &lm) {
     for (uint32_t k = kb; k < ke; k++) {                        // uniform; operands come in SGPRs
         uint32_t m = leaf_mask<T, R>(v, (T)a.lo[k], (T)a.span[k]);
@@ -261,7 +276,7 @@ __device__ __forceinline__ void apply_leaves_masks(const EvalArgs &a, uint32_t k
 
 // OR over the true rows of the truth table of AND over leaves (leaf or its complement).
 // When more than half of the table is true the complement is expanded instead.
-__device__ __forceinline__ uint32_t combine_masks(const EvalArgs &a, const LeafMasks &lm, uint32_t full) {
+__device__ __forceinline__ uint32_t combine_masks(CArgs &a, const LeafMasks &lm, uint32_t full) {
     const uint32_t n = a.n_leaves;
     const uint64_t all = n >= 6 ? ~0ull : ((1ull << (1u << n)) - 1ull);
     uint64_t tt = a.truth & all;
@@ -295,7 +310,7 @@ __device__ __forceinline__ void st_sc1(uint32_t *p, uint32_t v) { __hip_atomic_s
 // drop a builtin wait they can prove redundant)
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void store_mask(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t lane) {
+__device__ __forceinline__ void store_mask(CArgs &a, uint64_t step, uint32_t mbits, uint32_t lane) {
     const uint32_t w2 = (mbits & 0xFFFFu) | (dpp_or_zero<0xb1>(mbits) << 16);     // even lanes: own word | next lane's
     const uint32_t w2b = dpp_or_zero<0x4e>(w2);                                    // lanes 0 mod 4: the pair of lane + 2
     if ((lane & 3u) == 0)
@@ -304,7 +319,7 @@ __device__ __forceinline__ void store_mask(const EvalArgs &a, uint64_t step, uin
 
 // COUNT / FLAGS modes (grid-stride scan, no hand-off)
 template <int MODE>
-__device__ __forceinline__ void emit_step(const EvalArgs &a, uint64_t step, uint32_t mbits, uint32_t rpl_log2,
+__device__ __forceinline__ void emit_step(CArgs &a, uint64_t step, uint32_t mbits, uint32_t rpl_log2,
                                           uint64_t n_rows, uint32_t lane, uint64_t &wave_total) {
     static_assert(MODE != MODE_IDS, "ID output is the tile / expander form");
     wave_total += wave_sum_u32(__popc(mbits));
@@ -358,7 +373,7 @@ __device__ __forceinline__ void chain_leaf(const T (&v)[16], T lo, T span, bool 
 // Folds one evaluated half into the step's match count and (ID output, only if the half has a match)
 // into the lanes' match-bit words.
 template <int MODE, int H>
-__device__ __forceinline__ void fold_half(const EvalArgs &a, RowPlanes &acc, uint32_t &cnt, uint32_t &mbits) {
+__device__ __forceinline__ void fold_half(CArgs &a, RowPlanes &acc, uint32_t &cnt, uint32_t &mbits) {
     if (a.chain == 2) {                                         // OR form: NOT of the AND
 #pragma unroll
         for (int r = 0; r < 8; r++) acc.p[r] = ~acc.p[r];
@@ -382,7 +397,7 @@ __device__ __forceinline__ void fold_half(const EvalArgs &a, RowPlanes &acc, uin
 constexpr uint32_t kPartialSlots = 4096;
 
 template <int MODE>
-__device__ __forceinline__ void finish_totals(const EvalArgs &a, uint64_t wave_total) {
+__device__ __forceinline__ void finish_totals(CArgs &a, uint64_t wave_total) {
     static_assert(MODE != MODE_IDS, "ID output is the tile / expander form");
     __shared__ uint64_t s_tot[kWaves];
     if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = wave_total;
@@ -425,7 +440,7 @@ __device__ __forceinline__ uint32_t rows_below(uint64_t step_row0, uint64_t n_ro
 // ---- generic evaluators (any number of columns / leaves), RPL = 4 -----------------------
 // Fast path: all 1024 rows of the step exist and are contiguous.
 template <bool NT>
-__device__ __forceinline__ uint32_t eval_step_full(const EvalArgs &a, uint64_t step_row0, uint32_t lane) {
+__device__ __forceinline__ uint32_t eval_step_full(CArgs &a, uint64_t step_row0, uint32_t lane) {
     constexpr int R = 16;
     uint32_t idx[R];
 #pragma unroll
@@ -484,7 +499,7 @@ __device__ __forceinline__ uint32_t eval_step_full(const EvalArgs &a, uint64_t s
 // Guarded path (last partial step, gather mode): one chunk (4 rows per lane) at a time
 // with element loads.  `pos` counts rows of the scan / positions of the candidate list.
 template <bool GATHER>
-__device__ __forceinline__ uint32_t eval_step_guarded(const EvalArgs &a, uint64_t step_row0, uint64_t n_rows,
+__device__ __forceinline__ uint32_t eval_step_guarded(CArgs &a, uint64_t step_row0, uint64_t n_rows,
                                                       uint64_t begin, uint32_t lane) {
     uint32_t mbits = 0;
 #pragma unroll 1
@@ -572,7 +587,7 @@ struct alignas(16) FusedShared {
 struct Extent { uint64_t begin, n_rows, steps, groups; };
 
 template <bool GATHER>
-__device__ __forceinline__ Extent scan_extent(const EvalArgs &a) {
+__device__ __forceinline__ Extent scan_extent(CArgs &a) {
     Extent e;
     e.begin = 0;
     e.n_rows = a.n_rows;
@@ -610,7 +625,7 @@ __host__ __device__ inline uint32_t trailing_groups(uint32_t groups, uint32_t la
 // All in 32 bits (the host keeps a launch under 2^31 workgroups) and pinned to SGPRs: the role and everything
 // derived from it is wave-uniform, and a 64-bit division would be done -- and then kept -- in vector registers.
 template <int TPG>
-__device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
+__device__ __forceinline__ Role fused_role(CArgs &a, uint32_t groups) {
     constexpr uint32_t quad_tiles = 4u * TPG, period = quad_tiles + 1u;
     const uint32_t b = blockIdx.x;
     const uint32_t tile_quads = (groups + 3u) / 4u;
@@ -635,7 +650,7 @@ __device__ __forceinline__ Role fused_role(const EvalArgs &a, uint32_t groups) {
 
 // The two counters of a query (ctl) are the only words that need zeroing: the query does it for the NEXT
 // one, which uses the other half of a ping-pong pair (plain stores: the kernel boundary publishes them).
-__device__ __forceinline__ void zero_other_ctl(const EvalArgs &a) {
+__device__ __forceinline__ void zero_other_ctl(CArgs &a) {
     if (blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
 }
 
@@ -644,13 +659,13 @@ __device__ __forceinline__ void zero_other_ctl(const EvalArgs &a) {
 // agent-scope atomics that share a line are served one after the other, ~5 ns each); it is issued as soon as the
 // leader has left its wait and travels next to the group's match-word loads, so nothing waits for it alone.
 // Only the last of a shard goes on to the top counter, at the end of its work.
-__device__ __forceinline__ uint32_t ticket_draw(const EvalArgs &a, uint64_t g, uint32_t lane) {
+__device__ __forceinline__ uint32_t ticket_draw(CArgs &a, uint64_t g, uint32_t lane) {
     uint32_t t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(a.ctl + (uint32_t)(g % kCtlShards) * kCtlStride, 1u, PQPS_AGENT);
     return t;
 }
 
-__device__ __forceinline__ bool ticket_is_last(const EvalArgs &a, uint32_t ticket, uint64_t g, uint64_t groups, uint32_t lane) {
+__device__ __forceinline__ bool ticket_is_last(CArgs &a, uint32_t ticket, uint64_t g, uint64_t groups, uint32_t lane) {
     uint32_t last = 0;
     if (lane == 0) {
         const uint32_t shard = (uint32_t)(g % kCtlShards);
@@ -668,7 +683,7 @@ __device__ __forceinline__ bool ticket_is_last(const EvalArgs &a, uint32_t ticke
 // epoch: an expander that finds all count words of its group tagged with it knows the group's match words are
 // in memory.  One store instruction, no atomic, nothing to wait for.
 template <int TS>
-__device__ __forceinline__ void publish_tile(const EvalArgs &a, const FusedShared &sh, const Extent &ex, uint64_t tile, uint32_t lane) {
+__device__ __forceinline__ void publish_tile(CArgs &a, const FusedShared &sh, const Extent &ex, uint64_t tile, uint32_t lane) {
     const uint64_t first = tile * TS;
     const uint32_t steps_in_tile = ex.steps - first < (uint64_t)TS ? (uint32_t)(ex.steps - first) : (uint32_t)TS;
     if (tile == 0 && a.accumulate) {                            // gather: results are appended behind *out_count
@@ -687,10 +702,10 @@ __device__ __forceinline__ void publish_tile(const EvalArgs &a, const FusedShare
 // The SECOND tile of a group does the same one level up, for the supergroup that ended sum_lag groups ago -- from
 // its 4096 count words (16 KB read by one wave, once per 1024 tiles), not from its 64 group sums, so that the two
 // duties do not wait for each other.
-struct SumDuty { uint32_t c; uint32_t on; uint64_t g; };           // on: 1 = group sum, 2 = supergroup sum
+struct SumDuty { uint32_t c; uint32_t on; uint32_t g; };           // on: 1 = group sum, 2 = supergroup sum (on, g: wave-uniform)
 
 template <int TPG>
-__device__ __forceinline__ SumDuty sum_duty_load(const EvalArgs &a, uint32_t tile, uint32_t wv, uint32_t lane) {
+__device__ __forceinline__ SumDuty sum_duty_load(CArgs &a, uint32_t tile, uint32_t wv, uint32_t lane) {
     SumDuty d;
     d.c = 0; d.on = 0; d.g = 0;
     if (wv != 0) return d;                                          // uniform
@@ -698,15 +713,17 @@ __device__ __forceinline__ SumDuty sum_duty_load(const EvalArgs &a, uint32_t til
     if (t_in == 0 && q >= a.sum_lag) {
         d.g = q - a.sum_lag;
         d.on = 1;
-        d.c = ld_sc1(a.counts + d.g * kGroupSteps + lane);
+        d.c = ld_sc1(a.counts + (uint64_t)d.g * kGroupSteps + lane);
     } else if (t_in == 1 && q >= a.sum_lag && (q - a.sum_lag) % kSuperGroups == kSuperGroups - 1) {
         d.g = (q - a.sum_lag) / kSuperGroups;                       // the supergroup whose last group is q - sum_lag
         d.on = 2;
     }
+    d.g = uniform_u32(d.g);                                         // (kept in scalar registers through the tile's work)
+    d.on = uniform_u32(d.on);
     return d;
 }
 
-__device__ __forceinline__ void sum_duty_finish(const EvalArgs &a, const SumDuty &d, uint32_t lane) {
+__device__ __forceinline__ void sum_duty_finish(CArgs &a, const SumDuty &d, uint32_t lane) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
     if (d.on == 1) {
         if (__all((d.c >> kEpochShift) == a.epoch)) {
@@ -714,7 +731,7 @@ __device__ __forceinline__ void sum_duty_finish(const EvalArgs &a, const SumDuty
             if (lane == 0) st_sc1(a.gsum + d.g, tag | (uint64_t)sum);
         }
     } else if (d.on == 2) {
-        const uint64_t *pairs = (const uint64_t *)(a.counts + d.g * kSuperGroups * kGroupSteps);     // 2048 pairs of count words
+        const uint64_t *pairs = (const uint64_t *)(a.counts + (uint64_t)d.g * kSuperGroups * kGroupSteps);     // 2048 pairs of count words
         const uint64_t both = ((uint64_t)a.epoch << 48) | ((uint64_t)a.epoch << kEpochShift);
         bool ok = true;
         uint32_t sum = 0;
@@ -758,7 +775,7 @@ __device__ __forceinline__ uint32_t list_entry(const uint32_t *slot32, uint32_t 
     return (uint32_t)(two >> sft) & 0x3FFu;
 }
 
-__device__ __forceinline__ void store_list(const EvalArgs &a, uint32_t *stage32, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
+__device__ __forceinline__ void store_list(CArgs &a, uint32_t *stage32, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
     const uint32_t rpl = 1u << rl, chunks = 16u >> rl;              // rl = 2, 3, 4: 4, 2, 1 chunks
     if (lane < 32) stage32[lane] = 0u;
     uint32_t per = 0;
@@ -795,17 +812,17 @@ __device__ __forceinline__ void store_list(const EvalArgs &a, uint32_t *stage32,
 // per-lane counts, one LDS store per match) and the expander is left with a copy: four list entries + first row of
 // the step -> four IDs per lane and store.
 // (`step_uses_list16` must agree between the tile that writes and the expander that reads: both see the count word.)
-__device__ __forceinline__ bool step_uses_list16(const EvalArgs &a, uint32_t cnt, uint32_t rpl_log2) {
+__device__ __forceinline__ bool step_uses_list16(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
     return a.lists != nullptr && cnt > (uint32_t)a.list16_min[rpl_log2 >= 4u ? 1 : 0];
 }
 // the steps of a group that have a 128-byte slot to fetch (`cw` = a step's count word)
-__device__ __forceinline__ bool step_has_slot(const EvalArgs &a, uint32_t cw) {
+__device__ __forceinline__ bool step_has_slot(CArgs &a, uint32_t cw) {
     const uint32_t cnt = cw & kCountMask;
     return cnt != 0u && !step_uses_list16(a, cnt, (cw >> kRplShift) & 7u);
 }
 
 template <int RL>
-__device__ __forceinline__ void store_list16(const EvalArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t lane) {
+__device__ __forceinline__ void store_list16(CArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t lane) {
     constexpr uint32_t RPL = 1u << RL, CH = 16u >> RL;              // RL = 2, 3, 4: 4, 2, 1 chunks of 64 * RPL rows
     static_assert(RL >= 2 && RL <= 4, "widest predicate column: 8 / 4, 2 or 1 bytes");
     // rank of a lane's first match in each chunk: chunk by chunk, inside a chunk lane by lane (= ascending rows);
@@ -853,7 +870,7 @@ __device__ __forceinline__ void store_list16(const EvalArgs &a, uint16_t *stage,
 }
 
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
-__device__ __forceinline__ void tile_step_out(const EvalArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
+__device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
     if (step_uses_list16(a, cnt, rpl_log2)) {
         uint16_t *stage = (uint16_t *)sh.stage[threadIdx.x >> 6];                  // 2 KB per wave: 1024 entries
@@ -881,7 +898,7 @@ struct OutRing {
     uint64_t pos;                    // output slot of the oldest staged ID (= of the next ID when nothing is staged)
 };
 
-__device__ __forceinline__ void ring_flush(const EvalArgs &a, uint32_t *ring, OutRing &r, uint32_t lane, uint32_t n) {
+__device__ __forceinline__ void ring_flush(CArgs &a, uint32_t *ring, OutRing &r, uint32_t lane, uint32_t n) {
     // n <= 64 staged IDs leave in one store instruction
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the same wave wrote the ring
     const uint32_t v = ring[(r.head + lane) & (kStageRing - 1)];
@@ -942,7 +959,7 @@ __device__ __forceinline__ uint64_t sub_block_bits(uint32_t word, uint32_t s) {
 // Gather (index mode): the candidate numbers of a dense step's matching rows, all 16 sub-blocks requested at once
 // (lane L of sub-block s <-> row 64 s + L; a set bit implies the row lies inside the probed range): one memory
 // latency per step instead of one per sub-block.
-__device__ __forceinline__ void gather_candidates(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t lane, uint32_t (&cnd)[16]) {
+__device__ __forceinline__ void gather_candidates(CArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t lane, uint32_t (&cnd)[16]) {
     const uint32_t step_row0 = (uint32_t)(step * kStepRows);
 #pragma unroll
     for (uint32_t s = 0; s < 16; s++) {
@@ -956,7 +973,7 @@ __device__ __forceinline__ void gather_candidates(const EvalArgs &a, uint64_t be
 
 // A step with many matches: 64 rows at a time, rank inside the 64 = mbcnt, so the lanes store to consecutive slots.
 template <bool GATHER>
-__device__ __forceinline__ void expand_step_dense(const EvalArgs &a, uint64_t step, uint32_t word, uint32_t lane, uint32_t *ring, OutRing &r,
+__device__ __forceinline__ void expand_step_dense(CArgs &a, uint64_t step, uint32_t word, uint32_t lane, uint32_t *ring, OutRing &r,
                                                   const uint32_t (&cnd)[16]) {
     const uint32_t step_row0 = (uint32_t)(step * kStepRows);
     if (r.pending) ring_flush(a, ring, r, lane, r.pending);         // < 64 staged IDs from the steps before
@@ -982,7 +999,7 @@ __device__ __forceinline__ void expand_step_dense(const EvalArgs &a, uint64_t st
 
 // A step with few matches: one wave scan of the per-lane popcounts gives every lane its rank; the IDs go to the ring.
 template <bool GATHER>
-__device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t count, uint32_t lane,
+__device__ __forceinline__ void expand_step_sparse(CArgs &a, uint64_t begin, uint64_t step, uint32_t word, uint32_t count, uint32_t lane,
                                                    uint32_t *ring, OutRing &r) {
     const uint32_t step_row0 = (uint32_t)(step * kStepRows);
     const uint32_t cnt = __popc(word);
@@ -1007,7 +1024,7 @@ __device__ __forceinline__ void expand_step_sparse(const EvalArgs &a, uint64_t b
 // words of step L / 16 -- one wave scan ranks all IDs of the block, and the rank loop's trip count is that of the
 // fullest 64-row lane instead of four times that of the fullest 16-row lane.
 template <bool GATHER>
-__device__ __forceinline__ void expand_block16(const EvalArgs &a, uint64_t begin, uint64_t step0, uint32_t total, uint32_t nb,
+__device__ __forceinline__ void expand_block16(CArgs &a, uint64_t begin, uint64_t step0, uint32_t total, uint32_t nb,
                                                const uint16_t (*park)[64], uint32_t lane, uint32_t *ring, OutRing &r) {
     const uint32_t st = lane >> 4, q = lane & 15u;
     uint64_t w = *(const uint64_t *)(park[st] + 4u * q);
@@ -1037,7 +1054,7 @@ __device__ __forceinline__ void expand_block16(const EvalArgs &a, uint64_t begin
 // A step whose matches were left as 16-bit row numbers (store_list16): a copy.  Lane l of round q takes entries
 // 256 q + 4 l .. + 3 -- one 8-byte load, four adds, one 16-byte store (the output run of a step starts wherever the
 // matches in front of it end, so the store is only 4-byte aligned: global memory accesses may be).
-__device__ __forceinline__ void expand_step_list16(const EvalArgs &a, uint64_t step, uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
+__device__ __forceinline__ void expand_step_list16(CArgs &a, uint64_t step, uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     if (r.pending) ring_flush(a, ring, r, lane, r.pending);         // < 64 staged IDs from the steps before
     const uint64_t *src = (const uint64_t *)(a.lists + step * kStepRows) + lane;
@@ -1072,18 +1089,26 @@ __device__ __forceinline__ void expand_step_list16(const EvalArgs &a, uint64_t s
     r.pos += count;
 }
 
-// The same for a BLOCK of four consecutive steps (`which`: bit i = step0 + i left a 16-bit list; `cnt[i]` / `off[i]`: its
-// matches and its first output slot).  One step at a time the copy is a chain of memory latencies -- 138 entries are
-// one 276-byte load per wave, and 16 steps per wave one after the other made the expansion of a 13 % answer take 23 us
-// per group at 3.5 TB/s of copy traffic.  Here the first 512 entries of all four steps are requested before any is
-// awaited (8 loads in flight per wave); fuller steps get a second round.
-__device__ __forceinline__ void expand_block_list16(const EvalArgs &a, uint64_t step0, uint32_t which, const uint32_t (&cnt)[4], const uint64_t (&off)[4], uint32_t lane) {
+// The same for a BATCH of NS consecutive steps, NR rounds of 256 entries at a time (`which`: bit i = step0 + i left a
+// 16-bit list; lane l of `cw` / `my_off` holds count word and first output slot of step l of the group, step0 is step
+// `first` of it).  One step at a time the copy is a chain of memory latencies -- 138 entries are one 276-byte load per
+// wave, and 16 steps per wave one after the other made the expansion of a 13 % answer take 23 us per group at 3.5 TB/s of
+// copy traffic.  Here NS * NR = 8 loads are requested before any is awaited: eight steps of up to 256 matches each (what a
+// few-percent answer looks like), or four steps with their first 512; fuller steps come round again.
+template <int NS, int NR>
+__device__ __forceinline__ void expand_lists16(CArgs &a, uint64_t step0, uint32_t which, uint32_t cw, uint64_t my_off, uint32_t first, uint32_t lane) {
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-    uint32_t lim[4];
+    uint32_t lim[NS];
+    uint64_t off[NS];
+    uint32_t most = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) {
+    for (uint32_t i = 0; i < NS; i++) {
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(first + i)) & kCountMask;
+        off[i] = readlane_u64(my_off, (int)(first + i));
+        // entries that have a place in the caller's buffer (a result that does not fit is cut off, the count says so)
         const uint64_t room = off[i] < a.out_cap ? a.out_cap - off[i] : 0ull;
-        lim[i] = !((which >> i) & 1u) ? 0u : (room < (uint64_t)cnt[i] ? (uint32_t)room : cnt[i]);
+        lim[i] = !((which >> i) & 1u) ? 0u : (room < (uint64_t)cnt ? (uint32_t)room : cnt);
+        most = lim[i] > most ? lim[i] : most;
     }
     auto put = [&](uint32_t i, uint32_t q, uint64_t w) {
         const uint32_t e0 = q * 256u + lane * 4u;
@@ -1091,8 +1116,8 @@ __device__ __forceinline__ void expand_block_list16(const EvalArgs &a, uint64_t 
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         const uint32_t i0 = base + (lo & 0xFFFFu), i1 = base + (lo >> 16), i2 = base + (hi & 0xFFFFu), i3 = base + (hi >> 16);
         uint32_t *o = a.out_ids + off[i] + e0;
-        if (e0 + 4u <= lim[i]) {
-            u32x4_a4 v;
+        if (e0 + 4u <= lim[i]) {                                    // (the run of a step starts wherever the matches in front of it end:
+            u32x4_a4 v;                                             //  4-byte aligned, which global memory accesses may be)
             v.x = i0; v.y = i1; v.z = i2; v.w = i3;
             *(u32x4_a4 *)o = v;
         } else if (e0 < lim[i]) {                                   // the list's last lane: 1 - 3 entries
@@ -1101,30 +1126,26 @@ __device__ __forceinline__ void expand_block_list16(const EvalArgs &a, uint64_t 
             if (e0 + 2u < lim[i]) o[2] = i2;
         }
     };
+#pragma unroll 1
+    for (uint32_t q0 = 0; q0 * 256u < most; q0 += NR) {             // uniform
+        uint64_t w[NS][NR];
 #pragma unroll
-    for (uint32_t half = 0; half < 2; half++) {                     // entries [0, 512), then [512, 1024) of the steps that have them
-        if (half == 1 && lim[0] <= 512u && lim[1] <= 512u && lim[2] <= 512u && lim[3] <= 512u) break;     // uniform
-        uint64_t w[4][2];
+        for (uint32_t i = 0; i < NS; i++)
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
-#pragma unroll
-            for (uint32_t q = 0; q < 2; q++) {
+            for (uint32_t q = 0; q < NR; q++) {
                 w[i][q] = 0;
-                const uint32_t qq = 2u * half + q;
-                if (qq * 256u + lane * 4u < lim[i]) w[i][q] = ld_sc1((const uint64_t *)(a.lists + (step0 + i) * kStepRows) + qq * 64u + lane);
+                if ((q0 + q) * 256u + lane * 4u < lim[i]) w[i][q] = ld_sc1((const uint64_t *)(a.lists + (step0 + i) * kStepRows) + (q0 + q) * 64u + lane);
             }
 #pragma unroll
-        for (uint32_t i = 0; i < 4; i++)
+        for (uint32_t i = 0; i < NS; i++)
 #pragma unroll
-            for (uint32_t q = 0; q < 2; q++) {
-                const uint32_t qq = 2u * half + q;
-                if (qq * 256u < lim[i]) put(i, qq, w[i][q]);         // uniform
-            }
+            for (uint32_t q = 0; q < NR; q++)
+                if ((q0 + q) * 256u < lim[i]) put(i, q0 + q, w[i][q]);       // uniform
     }
 }
 
 template <bool GATHER>
-__device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
+__device__ __forceinline__ void expand_step(CArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
     if constexpr (!GATHER)
         if (step_uses_list16(a, count, rpl_log2)) { expand_step_list16(a, step, count, lane, ring, r); return; }   // uniform
@@ -1168,7 +1189,7 @@ __device__ __forceinline__ void expand_step(const EvalArgs &a, uint64_t begin, u
     expand_step_dense<GATHER>(a, step, word, lane, ring, r, cnd);
 }
 
-__device__ __forceinline__ bool word_valid(const EvalArgs &a, uint64_t w) { return (uint32_t)(w >> kWordEpochShift) == a.epoch; }
+__device__ __forceinline__ bool word_valid(CArgs &a, uint64_t w) { return (uint32_t)(w >> kWordEpochShift) == a.epoch; }
 
 // One look at what the expander of group g waits for, everything asked for in one round of loads.
 //   its own group     every count word of the group carries the epoch (=> the group's match words are in
@@ -1182,7 +1203,7 @@ __device__ __forceinline__ bool word_valid(const EvalArgs &a, uint64_t w) { retu
 // ascending order, so the caller can wait for that one word with one-load looks and come back for a full one
 // (which costs ~250 vector instructions) when it has appeared.
 template <int NEAR>
-__device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
+__device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
                                                uint32_t &cw, uint64_t &psum, uint64_t &own_super, const uint64_t *&watch) {
     uint32_t now = 0;
     const uint64_t step = g * kGroupSteps + lane;
@@ -1250,7 +1271,7 @@ __device__ __forceinline__ uint32_t poll_group(const EvalArgs &a, const Extent &
 // look, no waiting: a hint).  The words land in the wave's LDS slice, slot = step - c0, while the leader settles;
 // expand_range then finds them there instead of paying a memory latency after the barrier (2.8 us of the 7 us a
 // trailing group of Q_A took from settled to done).  Returns the steps requested (bits 0 .. 15) | 1 << 16, or 0.
-__device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
+__device__ __forceinline__ uint32_t prefetch_own_steps(CArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
                                                        uint32_t c0, uint32_t park) {
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1273,7 +1294,7 @@ __device__ __forceinline__ uint32_t prefetch_own_steps(const EvalArgs &a, FusedS
 // sparse branch of expand_range uses (slot k = the k-th non-empty step) -> returns 2 << 16 and the steps in `mask`;
 // otherwise the leader's own quarter as in prefetch_own_steps.
 // (`c`: lane l holds the count word of step l of the group, all 64 known to carry this query's epoch)
-__device__ __forceinline__ uint32_t leader_prefetch_with(const EvalArgs &a, FusedShared &sh, uint64_t g, uint32_t lane, uint32_t park,
+__device__ __forceinline__ uint32_t leader_prefetch_with(CArgs &a, FusedShared &sh, uint64_t g, uint32_t lane, uint32_t park,
                                                          uint32_t c, uint64_t &mask) {
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1297,7 +1318,7 @@ __device__ __forceinline__ uint32_t leader_prefetch_with(const EvalArgs &a, Fuse
     return bits | (1u << 16);
 }
 
-__device__ __forceinline__ uint32_t prefetch_as_leader(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
+__device__ __forceinline__ uint32_t prefetch_as_leader(CArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane,
                                                        uint32_t park, uint64_t &mask) {
     mask = 0;
     const uint64_t step = g * kGroupSteps + lane;
@@ -1318,7 +1339,7 @@ struct LeaderPrefetch { FusedShared *sh; uint32_t park; uint32_t pre; uint64_t m
 // (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
 // `pre` = what prefetch_own_steps returned for [c0, c0 + 16) (0: nothing is on its way).
 template <bool GATHER>
-__device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
+__device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
                                              uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0,
                                              uint64_t pre_mask = 0) {
     const uint32_t my_cnt = cw & kCountMask;
@@ -1381,29 +1402,34 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
                     const uint32_t k = (uint32_t)__builtin_ctz(rest);
                     if (lane < 32) __builtin_amdgcn_global_load_lds((global_cvoid *)(gmask + (size_t)k * 32), (lds_void *)&sh.mask[park][k][0], 4, 0, 16 /* sc1 */);
                 }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not count LDS-DMA as a write to LDS)
+            if (fetch) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler does not count LDS-DMA as a write to LDS)
             if (c0 == 0 && w0 == 0) PQPS_STAMP_GROUP(a, g, 5);
+        }
+        uint32_t lists16 = 0;                                       // steps of the window that left 16-bit lists: copied in batches
+        if constexpr (!GATHER) lists16 = bits & ~fetch;
+        if (lists16) {
+            const uint32_t big = uniform_u32((uint32_t)(__ballot(my_cnt > 256u) >> w0) & 0xFFFFu) & lists16;
+#pragma unroll 1
+            for (uint32_t h = 0; h < 2; h++) {                      // halves of 8 steps
+                const uint32_t lh = (lists16 >> (8 * h)) & 0xFFu;
+                if (!lh) continue;
+                if (!((big >> (8 * h)) & 0xFFu)) { expand_lists16<8, 1>(a, g * kGroupSteps + w0 + 8 * h, lh, cw, my_off, w0 + 8 * h, lane); continue; }
+#pragma unroll 1
+                for (uint32_t b = 0; b < 2; b++) {
+                    const uint32_t lb = (lh >> (4 * b)) & 0xFu;
+                    if (lb) expand_lists16<4, 2>(a, g * kGroupSteps + w0 + 8 * h + 4 * b, lb, cw, my_off, w0 + 8 * h + 4 * b, lane);
+                }
+            }
         }
         for (uint32_t bb = 0; bb < 4; bb++) {                       // blocks of 4 steps
             const uint32_t nb = (bits >> (4 * bb)) & 0xFu;
             if (!nb) continue;
             const uint32_t sidx0 = w0 + 4 * bb;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
-            uint32_t lb = 0;                                        // steps of the block that left 16-bit lists: copied together
-            if constexpr (!GATHER) lb = nb & ~((fetch >> (4 * bb)) & 0xFu);
+            const uint32_t lb = (lists16 >> (4 * bb)) & 0xFu;
             if (rpl_log2 == 4 && total <= kBlockIds && lb == 0u) {  // uniform
                 expand_block16<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
                 continue;
-            }
-            if (lb) {
-                uint32_t cnt4[4];
-                uint64_t off4[4];
-#pragma unroll
-                for (uint32_t i = 0; i < 4; i++) {
-                    cnt4[i] = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i)) & kCountMask;
-                    off4[i] = readlane_u64(my_off, (int)(sidx0 + i));
-                }
-                expand_block_list16(a, g * kGroupSteps + sidx0, lb, cnt4, off4, lane);
             }
             for (uint32_t i = 0; i < 4; i++) {
                 if (!((nb >> i) & 1u)) continue;
@@ -1433,7 +1459,7 @@ __device__ __forceinline__ void expand_range(const EvalArgs &a, FusedShared &sh,
 constexpr int kNearGroups = 6;     // supergroups in front whose group sums are read along with their words when a word is missing
 
 template <int NEAR>
-__device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
+__device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
                                              uint32_t &cw, uint64_t &psum, bool final_word = false, LeaderPrefetch *lp = nullptr) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
     uint64_t own_super = 0;
@@ -1492,7 +1518,7 @@ __device__ __forceinline__ bool settle_group(const EvalArgs &a, const Extent &ex
 
 // Recovery pass: see settle_group.  One wave, cold code.
 template <bool GATHER>
-__device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared &sh, const Extent &ex, uint32_t lane_in, uint32_t park) {
+__device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, const Extent &ex, uint32_t lane_in, uint32_t park) {
     uint32_t lane = lane_in;
     asm volatile("" : "+v"(lane));                                  // (keeps this cold code's address arithmetic out of the callers' registers)
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
@@ -1556,7 +1582,7 @@ __device__ __forceinline__ void recover_deferred(const EvalArgs &a, FusedShared 
 // An expander workgroup.  Among the scan tiles: four independent waves, one group each.  Behind the last tile:
 // one group, its leader wave settles it and hands count words and output slot to the other three through LDS.
 template <bool GATHER, bool LOOPED = false>                     // LOOPED: called again for further groups -- every wave reaches the barrier
-__device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShared &sh, const Extent &ex, const Role &role) {
+__device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, const Extent &ex, const Role &role) {
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
     const bool leader = !shared || wave == 0;
@@ -1638,7 +1664,8 @@ __device__ __forceinline__ void expander_workgroup(const EvalArgs &a, FusedShare
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
 template <int MODE, bool GATHER, bool NT = false>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) void eval_generic_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) void eval_generic_kernel(const EvalArgs) {
+    CArgs &a = kernel_args();
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if constexpr (MODE == MODE_IDS) {
         constexpr int TS = kWaves;                              // steps per tile
@@ -1660,7 +1687,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
             role.index = uniform_u32(blockIdx.x < layout_tiles ? blockIdx.x : blockIdx.x - layout_tiles);
             if (role.kind == ROLE_EXPAND_GROUP) {
                 for (Role r = role;;) {
-                    expander_workgroup<GATHER, true>(a, sh, ex, r);
+                    expander_workgroup<GATHER, true>(args_for_expanders(), sh, ex, r);
                     r.index += 4u * layout;
                     if (r.index / 4u >= ex.groups) break;
                     __syncthreads();                                // the workgroup's LDS hand-over is free again
@@ -1670,7 +1697,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
         } else {
             role = fused_role<kGroupSteps / TS>(a, layout);
             layout_tiles = ((layout + 3u) / 4u) * 4u * (uint32_t)(kGroupSteps / TS);
-            if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<GATHER>(a, sh, ex, role); return; }
+            if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<GATHER>(args_for_expanders(), sh, ex, role); return; }
         }
         if (role.kind != ROLE_SCAN) return;
         for (uint64_t tile = role.index; tile * TS < ex.steps; tile += layout_tiles) {
@@ -1776,7 +1803,7 @@ __device__ __forceinline__ void unpack64(const RawCol<W, RPL, U> &raw, uint64_t 
 }
 
 template <int W, int RPL, int U>
-__device__ __forceinline__ void eval_col_masks(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, LeafMasks &lm) {
+__device__ __forceinline__ void eval_col_masks(CArgs &a, int slot, const RawCol<W, RPL, U> &raw, LeafMasks &lm) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
         uint64_t v[16];
@@ -1790,7 +1817,7 @@ __device__ __forceinline__ void eval_col_masks(const EvalArgs &a, int slot, cons
 }
 
 template <int W, int RPL, int U, int H>
-__device__ __forceinline__ void eval_col_chain(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, RowPlanes &acc) {
+__device__ __forceinline__ void eval_col_chain(CArgs &a, int slot, const RawCol<W, RPL, U> &raw, RowPlanes &acc) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
         uint64_t v[16];
@@ -1805,7 +1832,7 @@ __device__ __forceinline__ void eval_col_chain(const EvalArgs &a, int slot, cons
 }
 
 template <int W, int RPL, int U>
-__device__ __forceinline__ void eval_col(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&idx)[16]) {
+__device__ __forceinline__ void eval_col(CArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&idx)[16]) {
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     if constexpr (W == 8) {
         uint64_t v[16];
@@ -1855,7 +1882,7 @@ __device__ __forceinline__ void valu_leaf(const T (&v)[16], T lo, T span, bool w
 }
 
 template <int W, int RPL, int U>
-__device__ __forceinline__ void eval_col_valu(const EvalArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&t)[16]) {
+__device__ __forceinline__ void eval_col_valu(CArgs &a, int slot, const RawCol<W, RPL, U> &raw, uint32_t (&t)[16]) {
     static_assert(W <= 4, "the vector-unit chain path is for columns of up to 4 bytes");
     const uint32_t kb = a.leaf_begin[slot], ke = a.leaf_begin[slot + 1];
     uint32_t v[16];
@@ -1873,13 +1900,13 @@ struct RawStep {
     RawCol<(W1 ? W1 : 1), RPL, U> r1;
     RawCol<(W2 ? W2 : 1), RPL, U> r2;
     template <bool NT>
-    __device__ __forceinline__ void load(const EvalArgs &a, uint64_t lane_row0) {
+    __device__ __forceinline__ void load(CArgs &a, uint64_t lane_row0) {
         r0.template load<NT>(a.col[0], lane_row0);
         if constexpr (W1 != 0) r1.template load<NT>(a.col[1], lane_row0);
         if constexpr (W2 != 0) r2.template load<NT>(a.col[2], lane_row0);
     }
     template <int MODE, int H>
-    __device__ __forceinline__ void eval_chain_half(const EvalArgs &a, uint32_t &cnt, uint32_t &mbits) const {
+    __device__ __forceinline__ void eval_chain_half(CArgs &a, uint32_t &cnt, uint32_t &mbits) const {
         RowPlanes acc;
 #pragma unroll
         for (int r = 0; r < 8; r++) acc.p[r] = ~0ull;
@@ -1904,7 +1931,7 @@ struct RawStep {
         }
     }
     template <int MODE, typename T>
-    __device__ __forceinline__ void one_leaf(const EvalArgs &a, const T (&v)[16], uint32_t &m, uint32_t &lane_total) const {
+    __device__ __forceinline__ void one_leaf(CArgs &a, const T (&v)[16], uint32_t &m, uint32_t &lane_total) const {
         const T lo = (T)a.lo[0], span = (T)a.span[0];
         const bool want = ((a.chain_want & 1u) != 0) != (a.chain == 2);      // OR form of one leaf = its negation
         if (span == 0) {                                                     // the six branches are wave-uniform
@@ -1926,7 +1953,7 @@ struct RawStep {
     // EV 0: ballots into SGPR planes (any chain); EV 1: ONE comparison on ONE column on the vector unit; EV 2: a chain over
     // narrow columns on the vector unit (valu_leaf).
     template <int MODE, int EV>
-    __device__ __forceinline__ void eval_chain_step(const EvalArgs &a, uint32_t &cnt, uint32_t &mbits, uint32_t &lane_total) const {
+    __device__ __forceinline__ void eval_chain_step(CArgs &a, uint32_t &cnt, uint32_t &mbits, uint32_t &lane_total) const {
         if constexpr (EV == 1) {
             static_assert(W1 == 0 && W2 == 0, "one column");
             uint32_t m = 0;
@@ -1967,7 +1994,7 @@ struct RawStep {
             eval_chain_half<MODE, 1>(a, cnt, mbits);
         }
     }
-    __device__ __forceinline__ uint32_t eval(const EvalArgs &a) const {     // <= 6 leaves: row-mask path
+    __device__ __forceinline__ uint32_t eval(CArgs &a) const {     // <= 6 leaves: row-mask path
         LeafMasks lm;
 #pragma unroll
         for (int k = 0; k < PQPS_TT_LEAVES; k++) lm.m[k] = 0;
@@ -1984,13 +2011,14 @@ struct RawStep {
 // wave has a byte of the table in flight -- which a one-shot workgroup pays on every launch.
 #define PQPS_HOIST_KERNARGS(a)                                                                        \
     asm volatile("" :: "s"((a).n_rows), "s"((a).col[0]), "s"((a).col[1]), "s"((a).col[2]), "s"(gridDim.x),  \
-                 "s"((a).masks), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask),     \
+                 "s"((a).masks), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask), "s"((a).lag), "s"((a).sum_lag), "s"((a).counts),     \
                  "s"((uint32_t)(a).leaf_begin[0]), "s"((uint32_t)(a).leaf_begin[1]), "s"((uint32_t)(a).leaf_begin[2]), \
                  "s"((uint32_t)(a).leaf_begin[3]))
 
 // General tree of <= 6 leaves (row-mask path).
 template <int MODE, int W0, int W1, int W2, bool NT>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 : 8) : 1) void eval_spec_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 : 8) : 1) void eval_spec_kernel(const EvalArgs) {
+    CArgs &a = kernel_args();
     // consecutive rows per lane per chunk: the widest column is one dwordx4 per chunk
     // (an 8-byte column: two, so that RPL stays in {4, 8, 16})
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
@@ -2006,7 +2034,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
         zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(a, sh, ex, role); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(args_for_expanders(), sh, ex, role); return; }
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step = (uint64_t)role.index * TS + wv;
         SumDuty duty;
@@ -2049,13 +2077,17 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
 // Measured, fraction of 8 TB/s at 100 M / 1 B rows: a lone 1-byte column wants 2 (COUNT 0.71 / 0.86;
 // 1 step: 0.56 / 0.48; 4: 0.72 / 0.86; 8: worse) -- 1 KB per wave and step is too little in flight; from
 // 2 bytes per row on, 1 is best (u16+u8: 0.83 / 0.82 against 0.80 / 0.82 with 2 and 0.77 / 0.80 with 4).
-constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 == 1 ? 2 : 1; }
+#ifndef PQPS_MULTI_BYTES
+#define PQPS_MULTI_BYTES 1
+#endif
+constexpr int chain_steps(int w0, int w1, int w2) { return w0 + w1 + w2 <= PQPS_MULTI_BYTES ? 2 : 1; }
 
 #ifndef PQPS_CHAIN_WGS
 #define PQPS_CHAIN_WGS 8
 #endif
 template <int MODE, int W0, int W1, int W2, int S, bool NT, int EV>
-__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void eval_chain_kernel(const EvalArgs a) {
+__global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void eval_chain_kernel(const EvalArgs) {
+    CArgs &a = kernel_args();
     constexpr int RPL = W0 == 8 ? 4 : 16 / W0;
     constexpr int U = 16 / RPL;
     PQPS_HOIST_KERNARGS(a);
@@ -2071,7 +2103,11 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void
         zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(a, sh, ex, role); return; }
+#ifdef PQPS_NO_EXPAND   /* experiments: what the scan tiles cost when the kernel holds nothing else (no results) */
+        if (role.kind >= ROLE_EXPAND_QUAD) return;
+#else
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(args_for_expanders(), sh, ex, role); return; }
+#endif
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step0 = (uint64_t)role.index * TS + (uint64_t)wv * S;
 #pragma unroll
