@@ -81,6 +81,7 @@ struct hipTable {
     record *row_block;                           /* contiguous host rows (all_records[i] point in); NULL: device only */
     size_t row_capacity;                         /* rows row_block / all_records have room for      */
     int device_only;                             /* the engine has no host rows (initializeEngineColumnsHIP / SyntheticHIP) */
+    int probe_bool;                              /* index mode probes BOOL indexes too (hipEngineProbeBoolIndexes) */
     struct hipLocks *locks;                      /* engine tables only; NULL for ad-hoc tables      */
     /* Several devices in one process (PQPS_DEVICES=0,1,...): the engine's rows are split into contiguous
      * shards by the reference's block partition (executeEngine-mpi.c:703-715), one device table each.

@@ -160,6 +160,15 @@ void releaseQueryHIP(struct hipQueryTicket *ticket);
 int hipEngineKernelTiming(struct engineS *engine, int enable);
 int hipEngineKernelTime(struct engineS *engine, double *scan_ms, double *query_ms, int *launches);
 
+/* Which of the reference's two SELECT row selections index mode follows.  Off (the default): QPESeq's -- only
+ * u64 / int indexes are probed (engine/serial/executeEngine-serial.c:377-433).  On: QPEOMP's / QPEMPI's -- BOOL indexes
+ * are probed as well (engine/omp/executeEngine-omp.c:424-459, same block in engine/mpi), which changes the answers of
+ * queries with a top-level condition on an indexed BOOL column: rows come back in the index's order (key ascending, row
+ * descending), a row once per probe that finds it, and an OR beside the probed condition loses its other side.  The
+ * one-thread order of that engine is reproduced (its append order across threads is a race).  Also switched on for a
+ * new engine by PQPS_PROBE_BOOL=1.  Returns the previous setting, -1 on a NULL engine. */
+int hipEngineProbeBoolIndexes(struct engineS *engine, int enable);
+
 /* Number of device shards the engine's table is split into (1 unless PQPS_DEVICES names several devices);
  * `rows` (may be NULL, room for that many entries) receives the rows each shard holds. */
 int hipEngineShards(struct engineS *engine, unsigned long long *rows, int capacity);

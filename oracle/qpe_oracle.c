@@ -325,6 +325,34 @@ static void range_i32(const record *rows, size_t off, const int *perm, int n,
     *e = l;
 }
 
+static void range_bool(const record *rows, size_t off, const int *perm, int n,
+                       int lo, int hi, int *b, int *e) {
+    int l = 0, r = n;
+    while (l < r) { int m = l + (r - l) / 2;
+        if ((int)*(const bool *)((const char *)&rows[perm[m]] + off) < lo) l = m + 1; else r = m; }
+    *b = l;
+    r = n;
+    while (l < r) { int m = l + (r - l) / 2;
+        if ((int)*(const bool *)((const char *)&rows[perm[m]] + off) <= hi) l = m + 1; else r = m; }
+    *e = l;
+}
+
+/* The key window the OpenMP / MPI engines derive for a condition on a BOOL index
+ * (engine/omp/executeEngine-omp.c:424-459; engine/mpi has the same block): = / != pick one key, the
+ * ordered operators the keys they admit -- `> true` and `< false` admit none (start > end). */
+static void bool_window(const char *op, const char *value, int *lo, int *hi) {
+    const int val = (strcasecmp(value, "true") == 0 || strcmp(value, "1") == 0) ? 1 : 0;
+    if (strcmp(op, "=") == 0) { *lo = val; *hi = val; }
+    else if (strcmp(op, "!=") == 0) { *lo = !val; *hi = !val; }
+    else {
+        *lo = 0; *hi = 1;
+        if (strcmp(op, ">") == 0) { if (!val) { *lo = 1; *hi = 1; } else { *lo = 1; *hi = 0; } }
+        else if (strcmp(op, ">=") == 0) { if (!val) { *lo = 0; *hi = 1; } else { *lo = 1; *hi = 1; } }
+        else if (strcmp(op, "<") == 0) { if (val) { *lo = 0; *hi = 0; } else { *lo = 1; *hi = 0; } }
+        else if (strcmp(op, "<=") == 0) { if (val) { *lo = 0; *hi = 1; } else { *lo = 0; *hi = 0; } }
+    }
+}
+
 /* executeQuerySelectSerial, S:358-474 (row selection only).
  * For every TOP-LEVEL condition in chain order (nested nodes have
  * attribute == NULL and are skipped, S:361-364) and every index whose name
@@ -340,6 +368,17 @@ long long orc_select_ids(const record *rows, int n,
                          const int *const *idx_perm,
                          const struct whereClauseS *wc,
                          uint32_t *out_ids, long long cap, long long *candidates) {
+    return orc_select_ids_v(rows, n, num_idx, idx_attr, idx_type, idx_perm, wc, out_ids, cap, candidates, 0);
+}
+
+/* `probe_bool` != 0: the row selection of executeQuerySelectOMP / ...MPI (omp:362-494) run by ONE thread -- the same
+ * walk, and BOOL indexes are probed too (omp:424-459).  (With several threads the reference appends the candidates
+ * of different indexes in whatever order the threads get there, omp:366,481: not a target.) */
+long long orc_select_ids_v(const record *rows, int n,
+                           int num_idx, const char *const *idx_attr, const int *idx_type,
+                           const int *const *idx_perm,
+                           const struct whereClauseS *wc,
+                           uint32_t *out_ids, long long cap, long long *candidates, int probe_bool) {
     bool any_index = false;
     long long out = 0, cand = 0;
     for (const struct whereClauseS *c = wc; c; c = c->next) {
@@ -366,6 +405,10 @@ long long orc_select_ids(const record *rows, int n,
                 else if (op == 3) { hi = (int)((unsigned)v - 1u); }
                 else if (op == 5) { hi = v; }
                 range_i32(rows, off, idx_perm[i], n, lo, hi, &b, &e);
+            } else if (probe_bool && idx_type[i] == FIELD_BOOL && real == FIELD_BOOL) {
+                int lo, hi;
+                bool_window(c->operator, c->value, &lo, &hi);
+                range_bool(rows, off, idx_perm[i], n, lo, hi, &b, &e);
             } else {
                 continue;                      /* S:425-433 */
             }

@@ -49,6 +49,13 @@ long long orc_select_ids(const record *rows, int n,
                          const int *const *idx_perm,
                          const struct whereClauseS *wc,
                          uint32_t *out_ids, long long cap, long long *candidates);
+/* the OpenMP / MPI engines' variant of the same walk when probe_bool != 0: BOOL indexes are probed too
+ * (engine/omp/executeEngine-omp.c:424-459), one thread */
+long long orc_select_ids_v(const record *rows, int n,
+                           int num_idx, const char *const *idx_attr, const int *idx_type,
+                           const int *const *idx_perm,
+                           const struct whereClauseS *wc,
+                           uint32_t *out_ids, long long cap, long long *candidates, int probe_bool);
 
 /* ---- projection -------------------------------------------------------- */
 /* Text of one cell as get_attribute_string_value produces it; buf >= 1100 B. */

@@ -333,6 +333,7 @@ def lib():
     L.releaseQueryHIP.argtypes = [vp]
     L.releaseQueryHIP.restype = None
     L.hipEngineBench.argtypes = [C.POINTER(E), C.c_int, W, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BenchResult)]
+    L.hipEngineProbeBoolIndexes.argtypes = [E, C.c_int]
     L.hipEngineKernelTiming.argtypes = [E, C.c_int]
     L.hipEngineKernelTime.argtypes = [E, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.pqps_malloc_mapped.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
@@ -657,6 +658,10 @@ class HipEngine:
         out = list(ids[:k])
         lib().free(ids)
         return out
+
+    def probe_bool_indexes(self, enable=True):
+        """Index mode follows QPEOMP / QPEMPI (BOOL indexes probed too, omp:424-459) instead of QPESeq; -> previous setting."""
+        return lib().hipEngineProbeBoolIndexes(self.e, 1 if enable else 0)
 
     def shards(self):
         """Rows held by each device shard (one entry unless PQPS_DEVICES names several devices)."""

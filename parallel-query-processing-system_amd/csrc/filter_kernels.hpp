@@ -1064,10 +1064,9 @@ __device__ __forceinline__ void expand_step_list16(CArgs &a, uint64_t step, uint
     const uint32_t lim = room < (uint64_t)count ? (uint32_t)room : count;
     uint64_t w[4];
 #pragma unroll
-    for (uint32_t q = 0; q < 4; q++) {
-        w[q] = 0;
-        if (q * 256u + lane * 4u < lim) w[q] = ld_sc1(src + q * 64u);
-    }
+    for (uint32_t q = 0; q < 4; q++)                                // (every lane loads, one wait: see expand_lists16)
+        w[q] = ld_sc1(q * 256u + lane * 4u < lim ? src + q * 64u : src - lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
         const uint32_t e0 = q * 256u + lane * 4u;
@@ -1133,9 +1132,16 @@ __device__ __forceinline__ void expand_lists16(CArgs &a, uint64_t step0, uint32_
         for (uint32_t i = 0; i < NS; i++)
 #pragma unroll
             for (uint32_t q = 0; q < NR; q++) {
-                w[i][q] = 0;
-                if ((q0 + q) * 256u + lane * 4u < lim[i]) w[i][q] = ld_sc1((const uint64_t *)(a.lists + (step0 + i) * kStepRows) + (q0 + q) * 64u + lane);
+                // every lane loads (a lane past the list's end: the list's first entries) -- no branch around a load, and
+                // ONE explicit wait for all of them below: gfx9's vmcnt counts loads and stores in one in-order queue, and
+                // left to itself the compiler put a vmcnt(0) in front of every step's stores (it cannot count loads behind
+                // branches), i.e. every step waited for the acknowledgement of the step's stores before it: eight memory
+                // round trips in a row, 10 us for the 16 steps of a wave (Q_A at 100 M rows: 14 us from settled to done)
+                const uint32_t e0 = (q0 + q) * 256u + lane * 4u;
+                w[i][q] = ld_sc1((const uint64_t *)(a.lists + (step0 + i) * kStepRows) + (e0 < lim[i] ? (q0 + q) * 64u + lane : 0u));
             }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        if (first == 0 && q0 == 0) PQPS_STAMP_GROUP(a, step0 / kGroupSteps, 7);
 #pragma unroll
         for (uint32_t i = 0; i < NS; i++)
 #pragma unroll

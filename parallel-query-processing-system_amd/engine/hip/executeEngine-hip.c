@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -107,7 +108,24 @@ static void key_window_i32(const char *op, const char *value, uint64_t *lo, uint
     *hi = (uint64_t)(uint32_t)h;
 }
 
-/* One index probe the serial engine would make for this WHERE (S:358-433), in its order. */
+/* The keys a condition on a BOOL index admits in the OpenMP / MPI engines (omp:424-459): = / != one key, the ordered
+ * operators what they admit; `> true` and `< false` admit none (lo > hi: the probe finds nothing, but it counts as a
+ * probe -- the query stays in index mode and comes back empty). */
+static void key_window_bool(const char *op, const char *value, uint64_t *lo, uint64_t *hi) {
+    const int val = (strcasecmp(value, "true") == 0 || strcmp(value, "1") == 0) ? 1 : 0;
+    int l = 0, h = 1;
+    if (strcmp(op, "=") == 0) { l = val; h = val; }
+    else if (strcmp(op, "!=") == 0) { l = !val; h = !val; }
+    else if (strcmp(op, ">") == 0) { l = 1; h = val ? 0 : 1; }
+    else if (strcmp(op, ">=") == 0) { l = val; h = 1; }
+    else if (strcmp(op, "<") == 0) { l = val ? 0 : 1; h = 0; }
+    else if (strcmp(op, "<=") == 0) { l = 0; h = val; }
+    *lo = (uint64_t)l;
+    *hi = (uint64_t)h;
+}
+
+/* One index probe the serial engine would make for this WHERE (S:358-433), in its order (with probe_bool: the
+ * OpenMP / MPI engines' one-thread order, omp:362-494 -- the same walk with BOOL indexes included). */
 struct probe { int index; uint64_t lo, hi; };
 
 static int list_probes(struct engineS *engine, const struct hipTable *t, struct whereClauseS *where, struct probe **out) {
@@ -125,6 +143,8 @@ static int list_probes(struct engineS *engine, const struct hipTable *t, struct 
                 key_window_u64(wc->operator, wc->value, &lo, &hi);
             else if (engine->attribute_types[i] == FIELD_INT && ix->key_kind == 1)
                 key_window_i32(wc->operator, wc->value, &lo, &hi);
+            else if (t->probe_bool && engine->attribute_types[i] == FIELD_BOOL && t->col[ix->column].width == 1 && ix->key_kind == 0)
+                key_window_bool(wc->operator, wc->value, &lo, &hi);
             else
                 continue;
             if (n == cap) {
@@ -968,6 +988,12 @@ bool evaluateWhereClause(record *r, struct whereClauseS *wc) {
 
 /* ---- lifecycle ------------------------------------------------------------------------ */
 
+/* PQPS_PROBE_BOOL=1: new engines follow the OpenMP / MPI engines' row selection (hipEngineProbeBoolIndexes) */
+static void probe_mode_from_env(struct engineS *engine) {
+    const char *env = getenv("PQPS_PROBE_BOOL");
+    if (env && atoi(env) != 0 && engine->record_block) ((struct hipTable *)engine->record_block)->probe_bool = 1;
+}
+
 struct engineS *initializeEngineHIP(int num_indexes, const char *indexed_attributes[],
                                     const int attribute_types[], const char *datafile,
                                     const char *tableName) {
@@ -987,6 +1013,7 @@ struct engineS *initializeEngineHIP(int num_indexes, const char *indexed_attribu
         if (!makeIndexHIP(engine, indexed_attributes[i], attribute_types[i]))
             fprintf(stderr, "Failed to create index for attribute: %s\n", indexed_attributes[i]);
     }
+    probe_mode_from_env(engine);
     TRACE("init: %d rows, CSV -> rows %.1f ms, rows -> device columns %.1f ms, %d indexes %.1f ms\n", engine->num_records,
           (t1 - t0) * 1e3, (t2 - t1) * 1e3, num_indexes, (now_seconds() - t2) * 1e3);
     return engine;
@@ -1011,6 +1038,7 @@ static void engine_indexes(struct engineS *engine, int num_indexes, const char *
     for (int i = 0; i < num_indexes; i++)
         if (!makeIndexHIP(engine, indexed_attributes[i], attribute_types[i]))
             fprintf(stderr, "Failed to create index for attribute: %s\n", indexed_attributes[i]);
+    probe_mode_from_env(engine);
 }
 
 struct engineS *initializeEngineColumnsHIP(unsigned long long num_rows, const struct hipColumnData columns[12],
@@ -1064,6 +1092,16 @@ bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const c
     const bool ok = makeIndexHIP(engine, attributeName, attributeType);
     hipTableUnlockExclusive(engine->record_block);
     return ok;
+}
+
+int hipEngineProbeBoolIndexes(struct engineS *engine, int enable) {
+    if (!engine || !engine->record_block) return -1;
+    struct hipTable *t = engine->record_block;
+    hipTableLockExclusive(t);                                       /* no query in flight while the mode changes */
+    const int before = t->probe_bool;
+    t->probe_bool = enable != 0;
+    hipTableUnlockExclusive(t);
+    return before;
 }
 
 int hipEngineKernelTiming(struct engineS *engine, int enable) {

@@ -44,4 +44,4 @@ for g in sel:
     tg = tg[tg > 0]
     print(f"  g {g:5d}: tiles end {us(tg.max()) if len(tg) else -1:6.1f}  start {us(start[g]):6.1f} counts seen {us(own[g]) if own[g] else -1:6.1f} "
           f"settled {us(res[g]):6.1f} done {us(done[g]):6.1f} polls {polls[g]}"
-          + (f"  [wave 0, sparse range: words in LDS {us(e[g, 5]):6.1f}, IDs out {us(e[g, 6]):6.1f}]" if e[g, 5] > 0 else ""))
+          + (f"  [wave 0: words in LDS {us(e[g, 5]):6.1f}," + (f" first lists in {us(e[g, 7]):6.1f}," if e[g, 7] > 0 else "") + f" IDs out {us(e[g, 6]):6.1f}]" if e[g, 5] > 0 else ""))

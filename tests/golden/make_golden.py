@@ -537,6 +537,67 @@ def wide_goldens(csv2k):
     (HERE / "select_wide_golden.json").write_text(json.dumps(out, separators=(",", ":")))
 
 
+BOOLPROBE_INDEX_CONFIGS = {
+    "default": q.DEFAULT_INDEXES,                      # connectEngine.c:48-62: sudo_used is a BOOL index
+    "bool_only": [("sudo_used", 3)],
+    "bool_twice": [("sudo_used", 3), ("risk_level", 1), ("sudo_used", 3)],
+}
+
+
+def boolprobe_cases():
+    """WHERE lists for the OpenMP / MPI engines' row selection (omp:362-494): every operator on the BOOL index with
+    every kind of literal, beside int / u64 probes, under OR, nested (no probe there), twice."""
+    cases = [
+        ("S1", [("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")]),
+        ("S2", [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")]),
+        ("S7", [("sudo_used", "=", "TRUE"), "OR", [("risk_level", "=", "5"), "AND", ("shell_type", "=", "bash")]]),
+        ("or_loses_a_side", [("sudo_used", "=", "TRUE"), "OR", ("user_name", "=", "student1030")]),
+        ("nested_is_not_probed", [("risk_level", ">", "3"), "AND", [("sudo_used", "=", "TRUE"), "OR", ("exit_code", "!=", "0")]]),
+        ("nested_only", [[("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "1")]]),
+        ("twice", [("sudo_used", "=", "TRUE"), "AND", ("sudo_used", "!=", "FALSE")]),
+        ("bool_then_int", [("sudo_used", "=", "TRUE"), "AND", ("exit_code", "=", "0")]),
+        ("int_then_bool", [("risk_level", ">=", "4"), "AND", ("sudo_used", "!=", "TRUE")]),
+        ("u64_and_bool", [("command_id", "<", "700"), "AND", ("sudo_used", "=", "1")]),
+        ("no_bool_condition", [("risk_level", ">", "3")]),
+        ("string_only", [("user_name", "=", "student1030")]),
+    ]
+    for op in ("=", "!=", ">", ">=", "<", "<="):
+        for lit in ("TRUE", "FALSE", "true", "1", "0", "maybe"):
+            cases.append((f"op_{op}_{lit}", [("sudo_used", op, lit), "AND", ("risk_level", ">", "0")] if lit == "maybe"
+                          else [("sudo_used", op, lit)]))
+    return cases
+
+
+def boolprobe_goldens(csv2k):
+    """select_boolprobe_golden.json: the row selection of executeQuerySelectOMP (oracle/_ref/libqpeomp_ref.so =
+    engine/omp + oracle/ref_harness_omp.c) with ONE thread.  Must be run with OMP_NUM_THREADS=1: with more, the
+    reference appends the candidates of different indexes in whatever order its threads arrive (omp:366,481)."""
+    import os
+    assert os.environ.get("OMP_NUM_THREADS") == "1", "run with OMP_NUM_THREADS=1"
+    if q.load_ref_omp() is None:
+        sys.exit("oracle/_ref/libqpeomp_ref.so missing: run `make -C oracle` in the authoring container")
+    q.build_oracle()
+    out = []
+    cols = ["command_id", "sudo_used", "risk_level", "user_name"]
+    for cfg, indexes in BOOLPROBE_INDEX_CONFIGS.items():
+        eng, orc = q.RefOmpEngine(csv2k, indexes), q.OracleTable(csv2k, indexes)
+        for name, chain in boolprobe_cases():
+            o_ids, o_count, cand = orc.select_ids(chain, probe_bool=True)
+            if cand > eng.n:                                    # would overflow the reference's candidate buffer (omp:346)
+                print(f"{name}/{cfg}: {cand} candidates for {eng.n} rows -- not sent to the reference")
+                continue
+            res = eng.select_where(cols, chain)
+            ids = [int(r[0]) for r in res["rows"]]
+            assert ids == o_ids, (name, cfg, len(ids), len(o_ids))
+            serial_ids, _, _ = orc.select_ids(chain)
+            out.append({"name": name, "csv": csv2k.name, "indexes": cfg, "where": q.chain_to_jsonable(chain), "candidates": cand,
+                        "num_records": res["numRecords"], "columns": res["columns"], "rows_sha256": sha_rows(res["rows"]),
+                        "ids_zlib_b64": q.pack_ids(ids), "differs_from_qpeseq": ids != serial_ids})
+        eng.close()
+    (HERE / "select_boolprobe_golden.json").write_text(json.dumps(out, separators=(",", ":")))
+    print(f"bool-probe cases: {len(out)} pinned, {sum(c['differs_from_qpeseq'] for c in out)} of them differ from QPESeq's answer")
+
+
 def driver_goldens(csv2k):
     """End-to-end driver goldens: the reference's QPESeq on its own sample-queries.txt and
     sample-queries-FULL.txt (which adds Sample 6, the DELETE).  The driver always opens
@@ -565,6 +626,8 @@ if __name__ == "__main__":
         driver_goldens(HERE / "commands_2k.csv")
     elif "--wide-only" in sys.argv:
         wide_goldens(HERE / "commands_2k.csv")
+    elif "--boolprobe-only" in sys.argv:
+        boolprobe_goldens(HERE / "commands_2k.csv")
     elif "--random-only" in sys.argv:
         random_goldens(HERE / "commands_2k.csv")
     else:

@@ -135,6 +135,10 @@ def load_oracle():
     lib.orc_load_csv.argtypes = [C.c_char_p, C.POINTER(C.POINTER(Record))]
     lib.orc_index_build.restype = C.c_int
     lib.orc_index_build.argtypes = [C.POINTER(Record), C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+    lib.orc_select_ids_v.restype = C.c_longlong
+    lib.orc_select_ids_v.argtypes = [C.POINTER(Record), C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_int)), C.POINTER(WhereClause),
+                                     C.POINTER(C.c_uint32), C.c_longlong, C.POINTER(C.c_longlong), C.c_int]
     lib.orc_select_ids.restype = C.c_longlong
     lib.orc_select_ids.argtypes = [C.POINTER(Record), C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                    C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_int)), W,
@@ -207,6 +211,51 @@ def load_ref():
     lib.get_attribute_string_value.argtypes = [C.POINTER(Record), C.c_char_p]
     _ref = lib
     return lib
+
+
+_ref_omp = False
+
+
+def load_ref_omp():
+    """The reference's OpenMP engine (+ oracle/ref_harness_omp.c); None when oracle/_ref was never built."""
+    global _ref_omp
+    if _ref_omp is not False:
+        return _ref_omp
+    so = ORACLE_DIR / "_ref" / "libqpeomp_ref.so"
+    if not so.exists():
+        _ref_omp = None
+        return None
+    lib = C.CDLL(str(so))
+    lib.refo_open.restype = C.c_void_p
+    lib.refo_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    lib.refo_close.argtypes = [C.c_void_p]
+    lib.refo_close.restype = None
+    lib.refo_num_records.argtypes = [C.c_void_p]
+    lib.refo_select_where.restype = C.c_longlong
+    lib.refo_select_where.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(WhereClause), C.c_char_p, C.c_longlong]
+    _ref_omp = lib
+    return lib
+
+
+class RefOmpEngine:
+    """QPEOMP's engine from oracle/_ref (in-container pinning only; run it with OMP_NUM_THREADS=1)."""
+
+    def __init__(self, csv_path, indexes):
+        self.lib = load_ref_omp()
+        self._names = c_str_array([a for a, _ in indexes])
+        self._types = c_int_array([t for _, t in indexes])
+        self.h = self.lib.refo_open(str(csv_path).encode(), len(indexes), self._names, self._types)
+        self.n = self.lib.refo_num_records(self.h)
+
+    def select_where(self, columns, chain):
+        wl = WhereList(chain)
+        items = c_str_array(columns or [])
+        return RefEngine._result(call_text(self.lib.refo_select_where, self.h, items, len(columns or []), wl.ptr))
+
+    def close(self):
+        if self.h:
+            self.lib.refo_close(self.h)
+            self.h = None
 
 
 def call_text(fn, *args, cap=1 << 16):
@@ -312,13 +361,14 @@ class OracleTable:
     def index_order(self, i):
         return list(self._perms[i][:self.n])
 
-    def select_ids(self, chain, cap=None):
+    def select_ids(self, chain, cap=None, probe_bool=False):
+        """probe_bool: the OpenMP / MPI engines' walk (BOOL indexes probed too), one thread."""
         wl = WhereList(chain)
         cap = cap if cap is not None else 8 * self.n + 16
         out = (C.c_uint32 * max(1, cap))()
         cand = C.c_longlong(0)
-        k = self.lib.orc_select_ids(self.rows, self.n, len(self.indexes), self._names, self._types,
-                                    self._permptrs, wl.ptr, out, cap, C.byref(cand))
+        k = self.lib.orc_select_ids_v(self.rows, self.n, len(self.indexes), self._names, self._types,
+                                      self._permptrs, wl.ptr, out, cap, C.byref(cand), 1 if probe_bool else 0)
         return list(out[:min(k, cap)]), k, cand.value
 
     def cell(self, row, attr):

@@ -612,6 +612,37 @@ def test_engine_select_matches_reference_golden(case):
         assert eng.count(chain) == case["num_records"]
 
 
+BOOLPROBE = json.loads((q.GOLDEN / "select_boolprobe_golden.json").read_text())
+BOOLPROBE_INDEX_CONFIGS = {
+    "default": pq.DEFAULT_INDEXES,
+    "bool_only": [("sudo_used", 3)],
+    "bool_twice": [("sudo_used", 3), ("risk_level", 1), ("sudo_used", 3)],
+}
+
+
+@pytest.mark.parametrize("cfg", sorted(BOOLPROBE_INDEX_CONFIGS))
+def test_engine_boolprobe_matches_qpeomp_golden(cfg):
+    """hipEngineProbeBoolIndexes: index mode follows QPEOMP / QPEMPI (BOOL indexes probed too, omp:424-459) -- the
+    compiled OpenMP engine's answers, one thread (select_boolprobe_golden.json); switched off again, QPESeq's."""
+    eng = pq.HipEngine(q.GOLDEN / "commands_2k.csv", BOOLPROBE_INDEX_CONFIGS[cfg])
+    orc = q.OracleTable(q.GOLDEN / "commands_2k.csv", BOOLPROBE_INDEX_CONFIGS[cfg])
+    assert eng.probe_bool_indexes(True) == 0
+    cases = [c for c in BOOLPROBE if c["indexes"] == cfg]
+    assert len(cases) > 20
+    for case in cases:
+        chain = q.chain_from_jsonable(case["where"])
+        ids = eng.select_ids(chain)
+        assert ids == q.case_ids(case), case["name"]
+        res = eng.select(case["columns"], chain)
+        assert res["success"] and res["numRecords"] == case["num_records"] and res["columns"] == case["columns"], case["name"]
+        assert sha_rows(res["rows"]) == case["rows_sha256"], case["name"]
+    assert eng.probe_bool_indexes(False) == 1
+    for case in cases[:12]:
+        chain = q.chain_from_jsonable(case["where"])
+        assert eng.select_ids(chain) == orc.select_ids(chain)[0], case["name"]
+    eng.close()
+
+
 def test_engine_index_order_matches_reference_btree(ctx):
     gold = json.loads((q.GOLDEN / "index_order_golden.json").read_text())
     for csv, per_attr in gold.items():

@@ -19,7 +19,7 @@ import qpelib as q
 pq = q.pq
 pytestmark = pytest.mark.gpu
 
-ENGINE_TESTS = ("engine_select_matches_reference_golden or kat_duplicates_and_ranges or kat_reference_unit_tests or "
+ENGINE_TESTS = ("engine_select_matches_reference_golden or engine_boolprobe or kat_duplicates_and_ranges or kat_reference_unit_tests or "
                 "linear_search_records or print_table_text or insert_then_delete or columnar_select or "
                 "concurrent_callers or qpehip_prints")
 

@@ -167,3 +167,34 @@ def test_partition_formula():
                 assert c.value in (n // world, n // world + 1)
                 pos += c.value
             assert pos == n
+
+
+BOOLPROBE = json.loads((GOLD / "select_boolprobe_golden.json").read_text())
+BOOLPROBE_INDEX_CONFIGS = {
+    "default": q.DEFAULT_INDEXES,
+    "bool_only": [("sudo_used", 3)],
+    "bool_twice": [("sudo_used", 3), ("risk_level", 1), ("sudo_used", 3)],
+}
+
+
+def test_oracle_boolprobe_matches_qpeomp_golden():
+    """The OpenMP / MPI engines' row selection (BOOL indexes probed too, engine/omp/executeEngine-omp.c:362-494, one
+    thread): orc_select_ids_v(..., probe_bool = 1) against the compiled reference's answers
+    (tests/golden/make_golden.py --boolprobe-only); and the serial walk differs exactly where the fixture says so."""
+    assert len(BOOLPROBE) > 100
+    tables = {}
+    differing = 0
+    for case in BOOLPROBE:
+        key = (case["csv"], case["indexes"])
+        if key not in tables:
+            tables[key] = q.OracleTable(GOLD / case["csv"], BOOLPROBE_INDEX_CONFIGS[case["indexes"]])
+        orc = tables[key]
+        chain = q.chain_from_jsonable(case["where"])
+        ids, k, cand = orc.select_ids(chain, probe_bool=True)
+        assert k == case["num_records"] and ids == q.case_ids(case), case["name"]
+        assert cand == case["candidates"], case["name"]
+        assert sha_rows(orc.project(ids, case["columns"])) == case["rows_sha256"], case["name"]
+        serial_ids, _, _ = orc.select_ids(chain)
+        assert (serial_ids != ids) == case["differs_from_qpeseq"], case["name"]
+        differing += serial_ids != ids
+    assert differing > 30
