@@ -739,8 +739,8 @@ def test_full_size_properties(ctx):
     flags_dev = ctx.malloc(n + 4096)
     rng = np.random.default_rng(1)
     try:
-        for name in ("S1", "Q_A", "Q_B", "Q_C"):
-            chain = QUERIES[name]
+        for name in ("S1", "Q_A", "Q_B", "Q_C", "dense_13_percent"):
+            chain = QUERIES[name] if name in QUERIES else [("risk_level", ">", "2")]       # (16-bit row lists in every step)
             ids = gpu_scan(ctx, dev, chain, out)
             k = len(ids)
             assert k > 0 and np.all(ids[1:] > ids[:-1]), name              # strictly ascending
