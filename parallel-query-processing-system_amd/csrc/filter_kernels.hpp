@@ -30,8 +30,8 @@
 // one wave publishes the epoch-tagged count words; the consumer polls with sc1 loads and reads the payload
 // with sc1 loads only.  Nothing has to be reset between queries (a stale word carries an older epoch).  No
 // result depends on dispatch order: an expander's wait is bounded, a group whose wait ran out is left to
-// the leader that is last to leave its wait (tickets: sharded atomics, the only ones in the launch; their
-// two words are zeroed by the query before, on the other half of a ping-pong pair), and a wait that never
+// the last group's leader once every leader is past its wait (sharded counters: the only atomics in the launch, no
+// return values; zeroed by the query before, on the other half of a ping-pong pair), and a wait that never
 // ends there sets the context's sticky status word.
 //
 // COUNT(*) / DELETE flags keep the grid-stride form of the scan (no ID list, no hand-off).
@@ -553,13 +553,13 @@ __device__ __forceinline__ uint32_t eval_step_guarded(CArgs &a, uint64_t step_ro
 // in the output, so no chain of waits forms, and an expander placed 3 * sum_lag groups behind its group's tiles
 // finds everything it needs at its first look.
 constexpr int kSuperGroups = 64;
-// ctl: the only words with atomic read-modify-writes, none of them on a path anything waits for.  An expander that
-// has finished adds 1 to the shard of its group (64 shards, a 128-byte line each: neighbouring groups finish at the
-// same time, and atomics that share a line serialise); the last of a shard adds 1 to the top word; the last of those
-// is the last expander of the launch -- the one that looks whether any group was given up on.
+// ctl: the only words with atomic read-modify-writes, none of them on a path anything waits for, none with a return
+// value.  A leader that is past its wait adds 1 to the shard of its group (64 shards, a 128-byte line each: neighbouring
+// groups get there at the same time, and atomics that share a line serialise).  The leader of the LAST group is the one
+// that looks whether any group was given up on -- once the shards add up to the number of groups, i.e. every leader is
+// past its wait (expanders_past_their_wait).
 constexpr int kCtlShards = 64, kCtlStride = 32;                     // u32 words per line
-constexpr int kCtlTop = kCtlShards * kCtlStride, kCtlDeferred = (kCtlShards + 1) * kCtlStride;
-constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;
+constexpr int kCtlWords = (kCtlShards + 2) * kCtlStride;            // (two spare lines)
 constexpr uint32_t kDirectIds = 192;        // a step with at most this many matches stages its IDs in LDS (a fuller one stores 64 rows at a time)
 constexpr uint32_t kBlockIds = 448;         // 1-byte columns: FOUR steps with at most this many matches between them are ranked as one block
 constexpr uint32_t kStageRing = 512;        // >= max(kDirectIds, kBlockIds) + 63
@@ -654,28 +654,26 @@ __device__ __forceinline__ void zero_other_ctl(CArgs &a) {
     if (blockIdx.x == 0 && threadIdx.x < kCtlShards + 2) a.zctl[threadIdx.x * kCtlStride] = 0u;
 }
 
-// Tickets of the expander leaders.  One leader of the launch -- the last to draw -- gets `true` from
-// ticket_is_last.  The draw is a returning atomic on the group's shard (64 shards on their own 128-byte lines:
-// agent-scope atomics that share a line are served one after the other, ~5 ns each); it is issued as soon as the
-// leader has left its wait and travels next to the group's match-word loads, so nothing waits for it alone.
-// Only the last of a shard goes on to the top counter, at the end of its work.
-__device__ __forceinline__ uint32_t ticket_draw(CArgs &a, uint64_t g, uint32_t lane) {
-    uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(a.ctl + (uint32_t)(g % kCtlShards) * kCtlStride, 1u, PQPS_AGENT);
-    return t;
+// A leader that has left its wait says so (and a group it gave up on is on record by then: settle_group drains).  No
+// return value: the first form drew tickets -- a returning atomic per leader, a second one for the last of each shard, then
+// a load, one after the other at the very end of the launch: 1 - 1.5 us on every ID query for a pass that never runs.
+// (low half of a shard's word: leaders past their wait; high half: those of them that gave their group up -- one
+// word, so that whoever sees all leaders through also sees what they left behind)
+__device__ __forceinline__ void leader_past_its_wait(CArgs &a, uint64_t g, uint32_t lane, bool gave_up) {
+    if (lane == 0) (void)__hip_atomic_fetch_add(a.ctl + (uint32_t)(g % kCtlShards) * kCtlStride, gave_up ? 0x10001u : 1u, PQPS_AGENT);
 }
 
-__device__ __forceinline__ bool ticket_is_last(CArgs &a, uint32_t ticket, uint64_t g, uint64_t groups, uint32_t lane) {
-    uint32_t last = 0;
-    if (lane == 0) {
-        const uint32_t shard = (uint32_t)(g % kCtlShards);
-        const uint32_t in_shard = (uint32_t)(groups / kCtlShards) + (shard < groups % kCtlShards ? 1u : 0u);
-        if (ticket + 1u == in_shard) {
-            const uint32_t shards = groups < (uint64_t)kCtlShards ? (uint32_t)groups : (uint32_t)kCtlShards;
-            last = __hip_atomic_fetch_add(a.ctl + kCtlTop, 1u, PQPS_AGENT) + 1u == shards ? 1u : 0u;
-        }
+// The last group's leader, at the end of its work: waits (bounded: they wait for scan tiles, which wait for nothing) until
+// every leader of the launch is past its wait, and tells whether any group was given up on.  One round of loads when
+// the others are through already, which is the rule: they started before this one.
+__device__ __forceinline__ bool expanders_past_their_wait(CArgs &a, uint64_t groups, uint32_t lane) {
+    const uint64_t deadline = wall_clock64() + kRecoverTicks;
+    for (;;) {
+        const uint32_t c = lane < kCtlShards ? ld_sc1(a.ctl + lane * kCtlStride) : 0u;
+        if ((uint64_t)wave_sum_u32(c & 0xFFFFu) >= groups) return wave_sum_u32(c >> 16) != 0u;     // (a shard has at most 1024 groups)
+        if (wall_clock64() > deadline) { if (lane == 0) st_sc1(a.status, 1u); return false; }
+        __builtin_amdgcn_s_sleep(16);
     }
-    return uniform_u32(last) != 0;
 }
 
 // End of a scan tile of TS steps.  Every wave has left the counts of its steps in sh.tile_cnt, drained its
@@ -1513,16 +1511,17 @@ __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_
     } else if (recovery || final_word) {
         if (lane == 0) st_sc1(a.status, 1u);                        // something never arrived: reported, never silent
     } else {
-        if (lane == 0) {
-            st_sc1(a.deferred + g, (a.epoch << kEpochShift) | (sum_out ? 3u : 1u));
-            __hip_atomic_fetch_add(a.ctl + kCtlDeferred, 1u, PQPS_AGENT);
-        }
-        drain_stores();                                             // ... in memory before this group counts as finished
+        if (lane == 0) st_sc1(a.deferred + g, (a.epoch << kEpochShift) | (sum_out ? 3u : 1u));
+        drain_stores();                                             // ... in memory before this leader says it is past its wait
     }
     return ok;
 }
 
-// Recovery pass: see settle_group.  One wave, cold code.
+// Recovery pass: see settle_group.  One wave, cold code -- and SMALL code: it used to call settle_group and expand_range
+// like every expander, and that second copy of the two made the kernels 55 KB instead of 33 and cost 150 bytes per
+// lane of spills, 1 - 1.5 us on every ID query.  Once the missing sums are out (first half) nothing has to be waited
+// for any more: every deferred group's count words are complete and every group sum in front of it is published, so
+// what is in front is a plain sum, and the group's steps are expanded one at a time.
 template <bool GATHER>
 __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, const Extent &ex, uint32_t lane_in, uint32_t park) {
     uint32_t lane = lane_in;
@@ -1537,13 +1536,12 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
             const uint64_t gg = p0 + (uint64_t)__builtin_ctzll(fw);
             fw &= fw - 1;
             uint32_t cw = 0;
-            uint64_t unused = 0;
             alive = false;
             const uint64_t deadline = wall_clock64() + kRecoverTicks;
 #pragma unroll 1
             for (uint32_t spins = 0; spins < kRecoverSpins; spins++) {
-                const uint64_t *nowatch = nullptr;
-                if (!(poll_group<0>(a, ex, gg, lane, 1u, cw, unused, unused, nowatch) & 1u)) { alive = true; break; }
+                cw = gg * kGroupSteps + lane < ex.steps ? ld_sc1(a.counts + gg * kGroupSteps + lane) : a.epoch << kEpochShift;
+                if (__all((cw >> kEpochShift) == a.epoch)) { alive = true; break; }
                 if (wall_clock64() > deadline) break;
                 __builtin_amdgcn_s_sleep(16);
             }
@@ -1568,6 +1566,8 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
         if (all) st_sc1(a.ssum + j, tag | sum);
     }
     drain_stores();
+    if (!alive) return;
+    uint32_t *ring = sh.stage[park];
 #pragma unroll 1
     for (uint64_t f0 = 0; f0 < ex.groups; f0 += 64) {               // pass 2: expand what was given up, in ascending order
         const uint32_t f = f0 + lane < ex.groups ? ld_sc1(a.deferred + f0 + lane) : 0u;
@@ -1575,12 +1575,40 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
         while (todo) {
             const uint64_t g = f0 + (uint64_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            uint32_t cw = 0;
-            uint64_t psum = 0;
-            if (!settle_group<kNearGroups>(a, ex, g, lane, kRecoverSpins, true, cw, psum)) continue;
-            const uint64_t base = a.accumulate ? ld_sc1(a.base_slot) : 0ull;
-            const uint32_t cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
-            expand_range<GATHER>(a, sh, ex, g, lane, 0, kGroupSteps, park, cnts, base + psum);
+            const uint32_t cw = g * kGroupSteps + lane < ex.steps ? ld_sc1(a.counts + g * kGroupSteps + lane) : a.epoch << kEpochShift;
+            uint64_t front = 0;
+            bool known = (cw >> kEpochShift) == a.epoch;
+#pragma unroll 1
+            for (uint64_t j = lane; j < g; j += 64) {               // the matches in front: every group sum before g
+                const uint64_t w = ld_sc1(a.gsum + j);
+                known = known && word_valid(a, w);
+                front += w & kWordMask;
+            }
+            if (!__all(known)) { if (lane == 0) st_sc1(a.status, 1u); continue; }       // (cannot be: pass 1 saw to both)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: the payload loads stay behind the looks
+            const uint32_t my_cnt = g * kGroupSteps + lane < ex.steps ? (cw & kCountMask) : 0u;
+            OutRing r;
+            r.head = 0;
+            r.pending = 0;
+            r.pos = (a.accumulate ? ld_sc1(a.base_slot) : 0ull) + wave_sum_u64(front);
+            if (g + 1 == ex.groups) {                               // (the last group's expander leaves the total)
+                const uint64_t total = r.pos + wave_sum_u32(my_cnt);
+                if (lane == 0) *a.out_count = total;
+            }
+#pragma unroll 1
+            for (uint64_t rest = __ballot(my_cnt != 0); rest; rest &= rest - 1) {        // one step at a time
+                const uint32_t st = (uint32_t)__builtin_ctzll(rest);
+                const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
+                const uint64_t step = g * kGroupSteps + st;
+                if (step_has_slot(a, cwi)) {                        // its 128 bytes into the wave's LDS slice, slot 0
+                    const uint32_t v = lane < 32 ? ld_sc1((const uint32_t *)(a.masks + step * 64) + lane) : 0u;
+                    if (lane < 32) ((uint32_t *)&sh.mask[park][0][0])[lane] = v;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                expand_step<GATHER>(a, ex.begin, step, sh.mask[park][0], (cwi >> kRplShift) & 7u, cwi & kCountMask, lane, ring, r);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the slot is filled again
+            }
+            if (r.pending) ring_flush(a, ring, r, lane, r.pending);
         }
     }
 }
@@ -1610,7 +1638,6 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         const uint64_t w = ld_sc1(a.gsum + g);
         if (word_valid(a, w) && (w & kWordMask) <= kSoloIds) return;        // uniform
     }
-    uint32_t ticket = 0;
     uint32_t pre = 0;
     uint64_t pre_mask = 0;
     if constexpr (!GATHER) {                                        // (a gather workgroup's waves take 4 steps each)
@@ -1638,7 +1665,7 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         pre_mask = lp.mask;
         __builtin_amdgcn_s_setprio(0);
         PQPS_STAMP_GROUP(a, g, 2);
-        if constexpr (!GATHER) ticket = ticket_draw(a, g, lane);    // past its wait (a group given up is on record by now)
+        if constexpr (!GATHER) leader_past_its_wait(a, g, lane, !ok);   // (a group given up is on record by now)
         if (ok) {
             cnts = g * kGroupSteps + lane < ex.steps ? (cw & 0xFFFFu) : 0u;
             group_off = (a.accumulate ? ld_sc1(a.base_slot) : 0ull) + psum;
@@ -1663,9 +1690,9 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
     }
     if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
-    // the leader that was last to leave its wait looks after the groups others gave up on (if any)
+    // the last group's leader looks after the groups others gave up on (if any), once all of them are past their waits
     if constexpr (!GATHER)
-        if (leader && ticket_is_last(a, ticket, g, ex.groups, lane) && ld_sc1(a.ctl + kCtlDeferred) != 0u) recover_deferred<GATHER>(a, sh, ex, lane, wave);
+        if (leader && g + 1 == ex.groups && expanders_past_their_wait(a, ex.groups, lane)) recover_deferred<GATHER>(a, sh, ex, lane, wave);
 }
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).

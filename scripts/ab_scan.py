@@ -17,6 +17,15 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402  (QUERIES, load_pkg)
 
+# selectivities between the bench's query shapes (tuning runs of the hand-over thresholds): ~1 %, ~2 %, ~5 % of the rows
+bench.QUERIES.update({
+    "Q_1pct": ([("risk_level", "=", "5")], "risk_level = 5"),
+    "Q_2pct": ([("risk_level", "=", "5"), "OR", ("exit_code", "=", "2")], "risk_level = 5 OR exit_code = 2"),
+    "Q_5pct": ([("exit_code", "!=", "0")], "exit_code != 0"),
+    "Q_none": ([("risk_level", ">", "9")], "risk_level > 9"),
+    "Q_01pct": ([("risk_level", "=", "5"), "AND", ("exit_code", "=", "2")], "risk_level = 5 AND exit_code = 2"),
+})
+
 
 def main():
     ap = argparse.ArgumentParser()
