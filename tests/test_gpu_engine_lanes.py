@@ -109,6 +109,36 @@ def test_synthetic_engine_index_mode(host):
         eng.close()
 
 
+def test_synthetic_engine_probes_bool_indexes_on_request(host):
+    """hipEngineProbeBoolIndexes on a device-only engine (the OpenMP / MPI engines' row selection, omp:424-459): a
+    top-level condition on the BOOL index is probed like the int ones -- rows in (key asc, row desc) order, once per
+    probe -- and without the switch it is not (QPESeq's selection).  Checker: the numpy index restatement that
+    tests/test_index_checker_pinned.py pins against the oracle, with the BOOL windows of omp:424-459 spelled out."""
+    eng = pq.HipEngine.synthetic(N, seed=SEED, indexes=[("sudo_used", 3), ("risk_level", 1)])
+    perms = {c: q.host_index_order(host.arr[c]) for c in ("sudo_used", "risk_level")}
+    imin, imax = -2**31, 2**31 - 1
+    cases = [
+        # (chain, probes with BOOL indexes probed, probes of the serial engine)
+        ([("sudo_used", "=", "TRUE")], [("sudo_used", 1, 1)], []),
+        ([("sudo_used", "!=", "TRUE"), "AND", ("risk_level", ">", "3")], [("sudo_used", 0, 0), ("risk_level", 4, imax)], [("risk_level", 4, imax)]),
+        ([("risk_level", "=", "5"), "AND", ("sudo_used", "=", "1")], [("risk_level", 5, 5), ("sudo_used", 1, 1)], [("risk_level", 5, 5)]),
+        ([("sudo_used", "=", "TRUE"), "OR", ("user_name", "=", "student1030")], [("sudo_used", 1, 1)], []),
+        ([("sudo_used", ">", "TRUE"), "OR", ("risk_level", "=", "5")], [("sudo_used", 1, 0), ("risk_level", 5, 5)], [("risk_level", 5, 5)]),
+        ([("sudo_used", "<=", "FALSE")], [("sudo_used", 0, 0)], []),
+    ]
+    try:
+        assert eng.probe_bool_indexes(True) == 0
+        for chain, probes, _serial in cases:
+            want = q.host_index_select(host, perms, probes, chain).tolist()
+            assert eng.select_ids(chain) == want, chain
+        assert eng.probe_bool_indexes(False) == 1
+        for chain, _probes, serial in cases:
+            want = (q.host_index_select(host, perms, serial, chain) if serial else host.oracle_scan(chain)).tolist()
+            assert eng.select_ids(chain) == want, chain
+    finally:
+        eng.close()
+
+
 def test_columns_engine_equals_synthetic_engine(engine, host):
     cols = {}
     for i, name in enumerate(pq.COLUMNS):
