@@ -643,6 +643,7 @@ def time_query(pq, L, ctx, tables, chain, mode, count, start, ids, cnt, sptr, to
             pq.check(L.pqps_qstream_scan(qs, cols, nc, count, start, C.byref(pred), ring[i][0].data_ptr(), ring[i][0].numel(), ring[i][1].data_ptr(), sptr))
         pq.check(L.pqps_qstream_sync(qs), "pqps_qstream_sync")
         torch.cuda.synchronize()
+        L.pqps_qstream_hint_answer(qs, matches, count)                 # (as the engine does when it has awaited a query: dense answers on one lane)
         t0 = time.perf_counter()
         for i in range(n_q):
             pred, cols, nc, _ = bound[i % len(bound)]

@@ -260,6 +260,11 @@ int pqps_qstream_scan(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols,
 int pqps_qstream_count(pqps_qstream *q, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                        const pqps_predicate *pred, uint64_t *out_count, void *scan_stream);
 int pqps_qstream_sync(pqps_qstream *q);
+/* What the last answer looked like (the caller knows once it has a count: the engine at awaitQueryHIP).  While
+ * answers hold a quarter of the rows or more, ID queries go to ONE lane: two dense expansions side by side get in each
+ * other's way (`risk_level > 1`, 43 % of 100 M rows: 124 us one at a time, 140 - 147 per query with two in flight), a
+ * sparse answer's end hides under the next query's scan.  Thread-safe against the issuing calls. */
+void pqps_qstream_hint_answer(pqps_qstream *q, uint64_t matches, uint64_t n_rows);
 /* Host time (ns) pqps_qstream_scan has spent waiting for an output pair to come free -- as opposed to time inside
  * runtime calls; `reset` != 0 clears the counter. */
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset);

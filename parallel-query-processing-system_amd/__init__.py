@@ -284,6 +284,8 @@ def lib():
     L.pqps_qstream_scan.argtypes = [vp, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
     L.pqps_qstream_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
     L.pqps_qstream_sync.argtypes = [vp]
+    L.pqps_qstream_hint_answer.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.pqps_qstream_hint_answer.restype = None
     L.pqps_qstream_scan_slot.argtypes = [vp, u32, C.POINTER(Column), u32, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
     L.pqps_qstream_count_slot.argtypes = [vp, u32, C.POINTER(Column), u32, u64, C.POINTER(Predicate), vp, vp]
     L.pqps_qstream_wait.argtypes = [vp, u32]

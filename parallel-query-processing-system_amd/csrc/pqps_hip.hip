@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <time.h>
 
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -1875,6 +1876,7 @@ struct pqps_qstream {
     bool *used;
     bool ordered;                    // the lanes already wait for the caller's stream
     uint64_t wait_ns;                // host time spent waiting for an output buffer to come free
+    std::atomic<int> dense;          // the last answers held a quarter of the rows or more: ID queries on one lane (pqps_qstream_hint_answer)
 };
 
 int pqps_qstream_destroy(pqps_qstream *q) {
@@ -1922,7 +1924,7 @@ bool one_lane_table(uint64_t n_rows) {
 
 // The slot is the caller's again (a host wait for the query that last used it, normally long satisfied), the lanes
 // come after what the caller's stream holds, and the query gets its lane.
-int qstream_begin(pqps_qstream *q, uint32_t slot, uint64_t n_rows, hipStream_t caller, pqps_ctx **lane) {
+int qstream_begin(pqps_qstream *q, uint32_t slot, uint64_t n_rows, hipStream_t caller, pqps_ctx **lane, bool ids = false) {
     if (slot >= q->depth) return fail(PQPS_EINVAL, "slot %u >= depth %u", slot, q->depth);
     if (q->used[slot]) { const uint64_t t0 = now_ns(); HIP_TRY(hipEventSynchronize(q->ready[slot])); q->wait_ns += now_ns() - t0; }
     if (!q->ordered) {                                           // what the caller's stream holds (the table, ...) comes first
@@ -1930,7 +1932,8 @@ int qstream_begin(pqps_qstream *q, uint32_t slot, uint64_t n_rows, hipStream_t c
         for (uint32_t i = 0; i < q->lanes; i++) HIP_TRY(hipStreamWaitEvent(q->child[i]->stream, q->joined, 0));
         q->ordered = true;
     }
-    *lane = q->child[one_lane_table(n_rows) ? 0u : (uint32_t)(q->seq % q->lanes)];
+    const bool one = one_lane_table(n_rows) || (ids && q->dense.load(std::memory_order_relaxed) != 0);
+    *lane = q->child[one ? 0u : (uint32_t)(q->seq % q->lanes)];
     return PQPS_OK;
 }
 
@@ -1957,7 +1960,7 @@ int qstream_issue(pqps_qstream *q, uint32_t slot, int mode, const pqps_column *c
         if (slot >= q->depth) return fail(PQPS_EINVAL, "slot %u >= depth %u", slot, q->depth);
         c = q->ctx;
     } else {
-        rc = qstream_begin(q, slot, n_rows, caller, &c);
+        rc = qstream_begin(q, slot, n_rows, caller, &c, mode == MODE_IDS);
         if (rc) return rc;
         s = c->stream;
     }
@@ -2012,6 +2015,10 @@ int pqps_qstream_lane(pqps_qstream *q, uint32_t slot, uint64_t n_rows, void *sca
     *lane_ctx = c;
     *lane_stream = (void *)c->stream;
     return PQPS_OK;
+}
+
+void pqps_qstream_hint_answer(pqps_qstream *q, uint64_t matches, uint64_t n_rows) {
+    if (q) q->dense.store(n_rows != 0 && matches >= n_rows / 4 ? 1 : 0, std::memory_order_relaxed);
 }
 
 int pqps_qstream_mark(pqps_qstream *q, uint32_t slot) {

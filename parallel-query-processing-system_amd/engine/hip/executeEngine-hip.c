@@ -440,6 +440,7 @@ static int query_await(struct query *q) {
                 again = true;
             }
             q->total += q->count[s];
+            if (rc == 0 && !q->count_only && q->n_probes == 0 && q->lane >= 0 && sh->qs) pqps_qstream_hint_answer(sh->qs, q->count[s], sh->n_rows);
         }
         if (rc != 0) return rc;
         if (!again) break;

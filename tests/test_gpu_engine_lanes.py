@@ -139,6 +139,33 @@ def test_synthetic_engine_probes_bool_indexes_on_request(host):
         eng.close()
 
 
+def test_dense_answers_move_the_stream_to_one_lane_and_back(engine, host):
+    """awaitQueryHIP tells the query stream what the answer looked like (pqps_qstream_hint_answer): while answers hold a
+    quarter of the rows or more, ID queries run on one lane.  Which lane a query ran on is not observable from here;
+    what is checked is that a run of dense, sparse and dense-again queries with several tickets in flight answers right."""
+    seq = ["dense", "dense", "S1", "dense", "Q_A", "S1", "dense", "dense", "Q_C"]
+    ctx = pq.Context(0)
+    tickets = []
+
+    def check(name0, t0):
+        n, res = engine.await_ticket(t0)
+        want = host.oracle_scan(CHAINS[name0])
+        got = np.zeros(max(n, 1), dtype=np.uint32)
+        if n:
+            ctx.download(got.ctypes.data, res.ids_dev, 4 * n)
+        assert n == len(want) and np.array_equal(got[:n], want), name0
+        engine.release_ticket(t0)
+    try:
+        for name in seq + seq:
+            tickets.append((name, engine.select_async(CHAINS[name])))
+            if len(tickets) == 3:
+                check(*tickets.pop(0))
+        for name0, t0 in tickets:
+            check(name0, t0)
+    finally:
+        ctx.close()
+
+
 def test_columns_engine_equals_synthetic_engine(engine, host):
     cols = {}
     for i, name in enumerate(pq.COLUMNS):
