@@ -22,6 +22,8 @@ QUERIES = {
     "u8": [("sudo_used", "=", "TRUE")],
     "none": [("risk_level", ">", "9")],
     "S7": [("sudo_used", "=", "TRUE"), "OR", [("risk_level", "=", "5"), "AND", ("shell_type", "=", "bash")]],
+    "dense": [("risk_level", ">", "1")],                      # 43 %: 16-bit row lists in every step
+    "u16": [("user_name", "=", "student1030")],
 }
 
 
