@@ -1454,9 +1454,9 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
 
 // The leader wave of group g settles what the group needs: waits (bounded) for its count words and for the sums
 // in front of it, publishes the group's own sum (and the supergroup's, if it is its last group) unless a tile
-// has done so, and takes its ticket.  Returns false if it gave the group up.
+// has done so.  Returns false if it gave the group up.
 //
-// Recovery: the ONE leader that is last to leave its wait looks after the groups others gave up on (which
+// Recovery: the LAST group's leader, once every leader is past its wait, looks after the groups others gave up on (which
 // in-order dispatch never produces).  By then every other expander is past its wait, so this wave is the
 // only one on the chip that waits for anything, and what it waits for are scan tiles, which wait for nothing.
 // It first publishes the sums that are missing, in ascending order, then expands the deferred groups.
