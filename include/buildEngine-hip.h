@@ -90,20 +90,35 @@ struct hipTable {
     int n_shards;
     struct hipTable **shard;
     uint64_t row0;                               /* engine row number of this shard's first row    */
+    /* One process per GPU (hipEngineJoinRanksHIP): this process holds rows [row0, row0 + n_rows) of a table that `world`
+     * processes hold between them; scan-mode SELECT / COUNT go through the exchange (pqps_exchange_*: the shard's scan +
+     * all-gatherv of the row numbers / all-reduce of the counts over RCCL, engine/mpi/executeEngine-mpi.c:745-765), whose
+     * ring slots are the table's lanes. */
+    pqps_exchange *xch;
+    int world, rank;
+    uint64_t rows_total;
 };
 
 #define HIP_MAX_SHARDS 16
 static inline int hipTableShards(const struct hipTable *t) { return t->n_shards > 1 ? t->n_shards : 1; }
 static inline struct hipTable *hipTableShard(struct hipTable *t, int s) { return t->n_shards > 1 ? t->shard[s] : t; }
 
-/* No-ops on a table without locks. */
+/* No-ops on a table without locks.  hipTableLockExclusive returns -1 (and takes nothing) when the calling thread holds a
+ * query lane -- a ticket of its own it has not released: the writer would wait for that ticket for ever. */
 void hipTableLockShared(struct hipTable *t);
 void hipTableUnlockShared(struct hipTable *t);
-void hipTableLockExclusive(struct hipTable *t);
+int  hipTableLockExclusive(struct hipTable *t);
 void hipTableUnlockExclusive(struct hipTable *t);
-/* A free query lane of the table (blocks while all are taken); -1 on a table without lanes. */
+/* A free query lane of the table; -1 on a table without lanes (the query then uses the table's own buffers).  Waits while
+ * all lanes are taken, but never for ever: HIP_LANE_REFUSED at once when the calling thread itself holds every lane, or
+ * after PQPS_LANE_WAIT_MS (default 10 000) without a lane coming free; the reason is on stderr. */
+#define HIP_LANE_REFUSED (-2)
 int  hipTableAcquireLane(struct hipTable *t);
 void hipTableReleaseLane(struct hipTable *t, int lane);
+int  hipTableLaneCount(const struct hipTable *t);
+/* test hooks: the gate alone on a table that has nothing else (tests/c/locks_test.c) */
+void hipTableLocksCreate(struct hipTable *t, int n_lanes);
+void hipTableLocksDestroy(struct hipTable *t);
 /* Issuing calls on the shards' query streams are serialised (they take microseconds). */
 void hipTableLockIssue(struct hipTable *t);
 void hipTableUnlockIssue(struct hipTable *t);
@@ -143,6 +158,10 @@ void destroyDeviceTableHIP(struct engineS *engine);
 struct hipColumnData;
 bool buildDeviceTableFromColumnsHIP(struct engineS *engine, unsigned long long num_rows, const struct hipColumnData *columns);
 bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed);
+/* rows [first_row, first_row + num_rows) of the seeded table, as ONE shard whose row numbers start at first_row (a rank's
+ * part of a table spread over several processes); `min_lanes`: at least that many query lanes */
+bool buildSyntheticShardDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed,
+                                       unsigned long long first_row, int min_lanes);
 /* Dictionary of a string column of the synthetic table (ascending strcmp order): the values behind the codes
  * pqps_synth_generate produces; NULL for a numeric column. */
 const char *const *hipSyntheticDictionary(int column, int *count);

@@ -148,10 +148,46 @@ struct hipDeviceResult {
     int n_shards;
     unsigned long long shard_count[16];/* matches found by each shard                                    */
 };
+/* Limits, so that no caller can wait for itself (the engine refuses instead of hanging a process that holds the GPU):
+ *   - a thread may hold at most hipEngineLanes(engine) unreleased tickets of one engine; asking for one more returns NULL at
+ *     once (reason on stderr).  Tickets held by SEVERAL threads can still add up to all lanes: a further request then waits
+ *     for a release, at most PQPS_LANE_WAIT_MS (default 10 000), and returns NULL after that;
+ *   - INSERT / DELETE / addAttributeIndexHIP / hipEngineProbeBoolIndexes / hipEngineKernelTiming wait until every ticket is
+ *     released; called from a thread that holds a ticket itself they are refused (false / success = false / -1).  While such
+ *     a call waits, threads that hold no ticket wait behind it with new queries; a thread that holds one may take more. */
+int hipEngineLanes(struct engineS *engine);
 struct hipQueryTicket *executeQuerySelectAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause);
 struct hipQueryTicket *executeQueryCountAsyncHIP(struct engineS *engine, struct whereClauseS *whereClause);
 long long awaitQueryHIP(struct hipQueryTicket *ticket, struct hipDeviceResult *result /* may be NULL */);
 void releaseQueryHIP(struct hipQueryTicket *ticket);
+/* out[0] = sum of the answer's row numbers, out[1] = sum of id[i] * (2 i + 1), mod 2^64 -- computed where the list lies,
+ * on the device; awaits the ticket first.  0, or -1 (a failed query, a COUNT ticket). */
+int hipQueryChecksumHIP(struct hipQueryTicket *ticket, unsigned long long out[2]);
+
+/* ---- one process per GPU: the reference's QPEMPI shape (QPEMPI.c:145-155: a C driver, one process per rank; the row
+ * partition and the exchange of engine/mpi/executeEngine-mpi.c:703-768) ----------------------------------------------
+ * Every process builds ITS rows of the table -- initializeEngineSyntheticRankHIP: rows [start, start + count) of the
+ * seeded table by the reference's block partition, row numbers table-wide -- on its own GPU (PQPS_DEVICE), then joins the
+ * others: rank 0 makes a 128-byte RCCL id (hipEngineRcclIdHIP) and hands it to the other ranks by whatever the host has (a
+ * file, MPI_Bcast, torch.distributed), every rank calls hipEngineJoinRanksHIP -- or its two halves with an agreement of
+ * the ranks in between, so that a rank that fails locally cannot leave the others inside the communicator's bring-up.
+ * From then on the engine's SELECT / COUNT are the TABLE's: executeQuerySelectAsyncHIP enqueues the shard's scan and the
+ * all-gatherv of the matching row numbers over RCCL (sizes, then exactly-sized payload at displacements, compact on the
+ * wire: pqps_exchange_select), awaitQueryHIP hands EVERY rank the whole ascending list on its device (count = matches in
+ * the table, shard_count[0] = this rank's); COUNT is the all-reduced count (mpi:745).  Rules: every rank issues the same
+ * queries in the same order (one issuing thread per process, or an order the host guarantees); scan-mode queries of one
+ * pass only (no index probes: the rank engines have no indexes); INSERT / DELETE are not exchanged.  `rccl_library`: the
+ * librccl.so to load (e.g. /opt/rocm/lib/librccl.so).  Every host wait of the exchange is bounded
+ * (PQPS_EXCHANGE_TIMEOUT_S): a query that cannot finish fails -- awaitQueryHIP returns -1 -- it never hangs. */
+struct engineS *initializeEngineSyntheticRankHIP(unsigned long long rows_total, unsigned long long seed, int world, int rank,
+                                                 const char *tableName);
+int hipEngineRcclIdHIP(const char *rccl_library, void *id128);
+int hipEngineJoinRanksHIP(struct engineS *engine, const char *rccl_library, const void *id128);
+int hipEngineJoinPrepareHIP(struct engineS *engine, const char *rccl_library);
+int hipEngineJoinConnectHIP(struct engineS *engine, const void *id128);
+int hipEngineLeaveRanksHIP(struct engineS *engine);
+/* payload bytes this rank has received: out[0] as they travelled, out[1] as u32 row numbers would have */
+int hipEngineWireBytesHIP(struct engineS *engine, unsigned long long out[2], int reset);
 
 /* Device time of the engine's queries AS THEY RUN on the lanes (several in flight): the recorders of the shards' query
  * streams (pqps_qstream_set_timing), events on the dispatch packets.  hipEngineKernelTime sums over the launches

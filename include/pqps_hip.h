@@ -53,6 +53,7 @@ extern "C" {
 #define PQPS_ENOMEM       -3
 #define PQPS_ENODEVICE    -4   /* no gfx950 device visible                         */
 #define PQPS_EOVERFLOW    -5   /* out_ids capacity too small for the matches       */
+#define PQPS_ETIMEOUT     -6   /* a bounded host wait of the exchange ran out: the communicator was aborted, the exchange is dead */
 
 #define PQPS_MAX_COLUMNS  12   /* columns of `record` (include/logType.h)          */
 #define PQPS_MAX_LEAVES   32   /* leaf comparisons in one WHERE tree               */
@@ -110,6 +111,10 @@ void pqps_ctx_destroy(pqps_ctx *ctx);
  * half a dozen device allocations, several ms). */
 int  pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
+/* Launch parameters of this context's ID queries (tests, A/B runs inside one process): "list16" 0 / 1 (the list area),
+ * "list16_min" / "list16_min_u8" (a step with more matches leaves a 16-bit list), "expand_lag" / "sum_lag" (groups),
+ * "tune" (bits); value < 0 restores the default. */
+int  pqps_ctx_set_option(pqps_ctx *ctx, const char *name, long value);
 int  pqps_device_count(void);
 int  pqps_ctx_device(pqps_ctx *ctx);
 /* Per-launch HIP-event timing of the filter (up to 4096 launches per reset).
@@ -281,13 +286,20 @@ int pqps_qstream_scan_slot(pqps_qstream *q, uint32_t slot, const pqps_column *co
                            const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *scan_stream);
 int pqps_qstream_count_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                             const pqps_predicate *pred, uint64_t *out_count, void *scan_stream);
-/* Host wait for the query of ONE slot; reports (once) a launch whose bounded waits ran out. */
+/* Host wait for the query of ONE slot; reports (once) a launch OF THIS SLOT whose bounded waits ran out (the launches are
+ * told apart by their epochs: two slots' queries may have run on the same lane). */
 int pqps_qstream_wait(pqps_qstream *q, uint32_t slot);
 /* A query that is more than one filter call (index probes + gather filters, flag passes in front of the last pass):
  * pqps_qstream_lane hands out the lane context + HIP stream the slot's query is to run on (call the pqps_filter_* /
  * pqps_index_probe functions with them), pqps_qstream_mark records its end on that stream. */
 int pqps_qstream_lane(pqps_qstream *q, uint32_t slot, uint64_t n_rows, void *scan_stream, pqps_ctx **lane_ctx, void **lane_stream);
 int pqps_qstream_mark(pqps_qstream *q, uint32_t slot);
+/* Takes the lanes' scratch (hand-off words, slots, the 2-bytes-per-row list area of ID scans) for tables of up to n_rows rows
+ * now rather than inside the first queries. */
+int pqps_qstream_reserve(pqps_qstream *q, uint64_t n_rows);
+/* Test hook: marks the slot's ID launch as one whose bounded waits ran out, the way the kernel does (its epoch in the lane's
+ * status words).  pqps_qstream_wait(slot) must report it -- once -- and no other slot's wait may. */
+int pqps_qstream_test_fail_slot(pqps_qstream *q, uint32_t slot);
 /* Per-launch timing of the queries AS THEY RUN IN THE STREAM (two in flight): the lanes' own recorders, events on
  * the dispatch packets (recording does not change how the launches overlap).  pqps_qstream_kernel_time = the sums of
  * pqps_ctx_kernel_time over the lanes. */
@@ -301,6 +313,15 @@ int pqps_qstream_kernel_time(pqps_qstream *q, double *eval_ms, double *total_ms,
  * ncclAllGather, the payload as ONE group of ncclSend / ncclRecv of exactly count[r] IDs between every pair of
  * ranks, landing at its displacement -- nothing padded on the wire, no compaction pass, and no receive buffer
  * that could be too small (the gathered list is grown to the sizes before the payload moves).
+ * WIRE FORM.  An answer of more than ~2 matches per 65 536 rows travels in compact form: the low 16 bits of every row number
+ * (relative to the shard's first row) + one u32 per 65 536-row group saying where the group's entries begin -- 2 bytes per
+ * match + 4 per group instead of 4 per match; the receiving GPU rebuilds the u32 IDs at the displacement (a copy kernel).
+ * The sender decides from its own count; the 32-byte-per-rank sizes all-gather carries (reported count, rows, first row,
+ * form), so every receiver sizes its receives alike.  PQPS_EXCHANGE_COMPACT=0: always u32 (A/B runs, tests).
+ * BOUNDED WAITS.  Every host wait of the exchange (a ring slot, the sizes, a result, pqps_exchange_sync) ends after
+ * PQPS_EXCHANGE_TIMEOUT_S seconds (default 30; 0 = unbounded): the communicator is aborted (ncclCommAbort -- which also
+ * ends the peers' matching calls), the call returns PQPS_ETIMEOUT and so does every later call on this exchange; the host
+ * falls back to another exchange path or tears down.  Nothing of this re-starts a process that holds the GPU.
  * One process per GPU; every rank makes the same calls in the same order.  RCCL is loaded at run time from
  * `rccl_library` (e.g. the librccl.so of the process's torch build, or /opt/rocm/lib/librccl.so); the
  * 128-byte id is produced on rank 0 and handed to the other ranks by whatever bootstrap the host has
@@ -347,7 +368,25 @@ int pqps_exchange_sync(pqps_exchange *x);
 /* Host time (ns) spent waiting -- for a ring slot to come free or for the sizes of a query -- as opposed to
  * time inside runtime / RCCL calls; `reset` != 0 clears the counter. */
 uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset);
+/* The compact wire form by itself, for a host that moves the payload with its own collectives (merge.py over
+ * torch.distributed): pqps_wire_pack reads a slot as the filter left it ([u64 count][u64][u32 IDs ...], `capacity` IDs), writes
+ * this rank's four header words (reported count, rows, first row, form: 1 = compact) to header_dev and -- if `enabled` and
+ * the compact form is smaller (pqps_wire_pays) -- the payload [u32 goff[groups + 1], padded to 16 bytes][u16 low[n]] to
+ * `wire` (room for pqps_wire_bytes(n_rows, min(capacity, n_rows))); pqps_wire_expand turns a received payload into u32 IDs
+ * at out_ids (the list's displacement in the gathered list). */
+uint64_t pqps_wire_bytes(uint64_t n_rows, uint64_t n_ids);
+int pqps_wire_pays(uint64_t n_rows, uint64_t n_ids);
+int pqps_wire_pack(pqps_ctx *ctx, const uint32_t *slot, uint64_t capacity, uint64_t n_rows, uint32_t id_base, int enabled,
+                   uint64_t *header_dev, void *wire, void *stream);
+int pqps_wire_expand(pqps_ctx *ctx, const void *wire, uint64_t n_rows, uint32_t id_base, uint32_t *out_ids, void *stream);
+/* Payload bytes this rank has RECEIVED from its peers so far: out[0] as they travelled (compact or u32), out[1] what the
+ * same lists are as u32 IDs; `reset` != 0 clears both. */
+void pqps_exchange_wire_bytes(pqps_exchange *x, uint64_t out[2], int reset);
 int pqps_exchange_destroy(pqps_exchange *x);
+
+/* Checksums of a device-resident ID list: out[0] = sum of ids[i], out[1] = sum of ids[i] * (2 i + 1), both mod 2^64 (the
+ * second depends on the order).  Synchronous; what a bench or a test compares two lists with without downloading them. */
+int pqps_ids_checksum(pqps_ctx *ctx, const uint32_t *ids, uint64_t count, uint64_t out[2], void *stream);
 
 /* Row-range block partition of engine/mpi/executeEngine-mpi.c:703-715. */
 void pqps_partition(uint64_t n_rows, int world, int rank, uint64_t *start, uint64_t *count);

@@ -111,7 +111,8 @@ class DeviceResult(C.Structure):
 class BenchResult(C.Structure):
     """struct hipBenchResult (include/engineBench.h)."""
     _fields_ = [("seconds", C.c_double), ("queries", C.c_longlong), ("matches", C.c_longlong), ("mismatches", C.c_longlong),
-                ("issue_seconds", C.c_double), ("await_seconds", C.c_double)]
+                ("issue_seconds", C.c_double), ("await_seconds", C.c_double),
+                ("want_checksum", C.c_int), ("have_checksum", C.c_int), ("checksum", C.c_ulonglong * 2)]
 
 
 class EngineS(C.Structure):
@@ -232,6 +233,24 @@ def build_library():
     subprocess.run(["make", "-s", "-C", str(PKG_DIR)], check=True)
 
 
+_bench_lib = None
+
+
+def bench_lib():
+    """libpqps_bench.so: the lab bench above the engine API (host/engineBench.c) -- not part of the product library."""
+    global _bench_lib
+    if _bench_lib is None:
+        lib()                                                    # the product first: the bench library links against it
+        path = PKG_DIR / "libpqps_bench.so"
+        if not path.exists():
+            raise PqpsError(f"{path} is missing: build it with `make -C {PKG_DIR}`")
+        B = C.CDLL(str(path))
+        B.hipEngineBench.argtypes = [C.POINTER(C.POINTER(EngineS)), C.c_int, C.POINTER(WhereClause), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(BenchResult)]
+        _bench_lib = B
+    return _bench_lib
+
+
 def lib():
     """The product shared object.  Never falls back to anything else."""
     global _lib
@@ -253,6 +272,7 @@ def lib():
     L.pqps_ctx_destroy.restype = None
     L.pqps_ctx_sync.argtypes = [vp, vp]
     L.pqps_ctx_reserve.argtypes = [vp, u64]
+    L.pqps_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     L.pqps_ctx_set_timing.argtypes = [vp, C.c_int]
     L.pqps_ctx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.pqps_device_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(u64)]
@@ -306,6 +326,13 @@ def lib():
     L.pqps_exchange_count.argtypes = [vp, C.POINTER(Column), u32, u64, C.POINTER(Predicate), u32, vp]
     L.pqps_exchange_result.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.pqps_exchange_sync.argtypes = [vp]
+    L.pqps_exchange_wire_bytes.argtypes = [vp, C.POINTER(u64), C.c_int]
+    L.pqps_wire_bytes.argtypes = [u64, u64]
+    L.pqps_wire_bytes.restype = u64
+    L.pqps_wire_pays.argtypes = [u64, u64]
+    L.pqps_wire_pack.argtypes = [vp, vp, u64, u64, u32, C.c_int, vp, vp, vp]
+    L.pqps_wire_expand.argtypes = [vp, vp, u64, u32, vp, vp]
+    L.pqps_exchange_wire_bytes.restype = None
     L.pqps_exchange_destroy.argtypes = [vp]
     L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.hipCompileWherePlan.argtypes = [C.POINTER(Schema), W, C.POINTER(Plan), C.c_char_p, C.c_size_t]
@@ -334,7 +361,19 @@ def lib():
     L.awaitQueryHIP.argtypes = [vp, C.POINTER(DeviceResult)]
     L.releaseQueryHIP.argtypes = [vp]
     L.releaseQueryHIP.restype = None
-    L.hipEngineBench.argtypes = [C.POINTER(E), C.c_int, W, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(BenchResult)]
+    L.hipEngineLanes.argtypes = [E]
+    L.initializeEngineSyntheticRankHIP.restype = E
+    L.initializeEngineSyntheticRankHIP.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_int, C.c_int, C.c_char_p]
+    L.hipEngineRcclIdHIP.argtypes = [C.c_char_p, vp]
+    L.hipEngineJoinRanksHIP.argtypes = [E, C.c_char_p, vp]
+    L.hipEngineJoinPrepareHIP.argtypes = [E, C.c_char_p]
+    L.hipEngineJoinConnectHIP.argtypes = [E, vp]
+    L.hipEngineLeaveRanksHIP.argtypes = [E]
+    L.hipEngineWireBytesHIP.argtypes = [E, C.POINTER(C.c_ulonglong), C.c_int]
+    L.hipQueryChecksumHIP.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.pqps_ids_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), vp]
+    L.pqps_qstream_reserve.argtypes = [vp, u64]
+    L.pqps_qstream_test_fail_slot.argtypes = [vp, u32]
     L.hipEngineProbeBoolIndexes.argtypes = [E, C.c_int]
     L.hipEngineKernelTiming.argtypes = [E, C.c_int]
     L.hipEngineKernelTime.argtypes = [E, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -478,6 +517,15 @@ class Context:
     def set_timing(self, on=True):
         check(lib().pqps_ctx_set_timing(self.h, 1 if on else 0))
 
+    def set_option(self, name, value):
+        check(lib().pqps_ctx_set_option(self.h, name.encode(), int(value)), "pqps_ctx_set_option")
+
+    def ids_checksum(self, ids_dev, count, stream=None):
+        """(sum of ids, sum of ids[i] * (2 i + 1)) mod 2^64 of a device-resident list (pqps_ids_checksum)."""
+        out = (C.c_uint64 * 2)()
+        check(lib().pqps_ids_checksum(self.h, ids_dev, int(count), out, stream), "pqps_ids_checksum")
+        return int(out[0]), int(out[1])
+
     def kernel_time(self):
         """-> (ms in the scan kernel, ms in the whole query, launches) summed since the last call (an ID query is one launch: both equal)."""
         ev, tot, k = C.c_double(), C.c_double(), C.c_int()
@@ -604,6 +652,51 @@ class HipEngine:
             raise PqpsError("initializeEngineSyntheticHIP failed")
         self.n = self.e.contents.num_records
         return self
+
+    @classmethod
+    def synthetic_rank(cls, rows_total, world, rank, seed=0x5EED):
+        """initializeEngineSyntheticRankHIP: this process's rows of a table that `world` processes hold between them
+        (not joined yet: join_ranks / join_prepare + join_connect)."""
+        self = cls.__new__(cls)
+        self.e = lib().initializeEngineSyntheticRankHIP(rows_total, seed, world, rank, b"commands")
+        if not self.e:
+            raise PqpsError("initializeEngineSyntheticRankHIP failed")
+        self.n = self.e.contents.num_records
+        return self
+
+    @staticmethod
+    def rccl_id(rccl_library):
+        ident = C.create_string_buffer(128)
+        if lib().hipEngineRcclIdHIP(str(rccl_library).encode(), ident) != 0:
+            raise PqpsError("hipEngineRcclIdHIP failed: " + lib().pqps_last_error().decode())
+        return ident.raw
+
+    def join_prepare(self, rccl_library):
+        if lib().hipEngineJoinPrepareHIP(self.e, str(rccl_library).encode()) != 0:
+            raise PqpsError("hipEngineJoinPrepareHIP failed: " + lib().pqps_last_error().decode())
+
+    def join_connect(self, ident):
+        if lib().hipEngineJoinConnectHIP(self.e, C.create_string_buffer(ident, 128)) != 0:
+            raise PqpsError("hipEngineJoinConnectHIP failed: " + lib().pqps_last_error().decode())
+
+    def join_ranks(self, rccl_library, ident):
+        self.join_prepare(rccl_library)
+        self.join_connect(ident)
+
+    def leave_ranks(self):
+        lib().hipEngineLeaveRanksHIP(self.e)
+
+    def wire_bytes(self, reset=False):
+        out = (C.c_ulonglong * 2)()
+        lib().hipEngineWireBytesHIP(self.e, out, 1 if reset else 0)
+        return int(out[0]), int(out[1])
+
+    def ticket_checksum(self, ticket):
+        """(sum of the row numbers, sum of id[i] * (2 i + 1)) mod 2^64 of the ticket's answer, computed on the device."""
+        out = (C.c_ulonglong * 2)()
+        if lib().hipQueryChecksumHIP(ticket, out) != 0:
+            raise PqpsError("hipQueryChecksumHIP failed")
+        return int(out[0]), int(out[1])
 
     @classmethod
     def from_columns(cls, n_rows, columns, indexes=()):

@@ -69,7 +69,7 @@ struct EvalArgs {
     uint32_t *ctl;                   // [kCtlWords] expanders past their wait, deferred groups (zero at launch)
     uint32_t *zctl;                  // the other half of the ctl pair: zeroed here for the query after this one
     uint64_t *base_slot;             // gather: first output slot (= *out_count when the launch began)
-    uint32_t *status;                // sticky error word of the context (a wait that never ended)
+    uint32_t *status;                // [kStatusWords] error words of the context (a wait that never ended): word epoch % kStatusWords = epoch
     uint32_t *out_ids;
     uint64_t out_cap;
     uint64_t *out_count;
@@ -570,8 +570,13 @@ constexpr uint32_t kRecoverSpins = 1u << 26; // "the long wait" (recovery pass, 
 // When it runs out the sticky status word is set; the host reports it once and resets the hand-off words.
 constexpr uint64_t kRecoverTicks = 25000000ull;
 constexpr uint32_t kCountMask = 0x7FFu;     // matches of a step: 0 .. 1024
+// The status words name the LAUNCH that gave up (its epoch, in the word epoch % kStatusWords): two queries of a query
+// stream can run on one lane context, and whoever awaits one of them must not be told about the other's failure.
+constexpr uint32_t kStatusWords = 64;
 constexpr int kRplShift = 11, kEpochShift = 16, kWordEpochShift = 48;
 constexpr uint64_t kWordMask = (1ull << kWordEpochShift) - 1ull;
+
+__device__ __forceinline__ void report_gave_up(CArgs &a) { st_sc1(a.status + (a.epoch & (kStatusWords - 1u)), a.epoch); }
 
 struct alignas(16) FusedShared {
     uint16_t mask[kWaves][kGroupSteps / kWaves][64];   // expander waves: match words of 16 steps at a time
@@ -671,7 +676,7 @@ __device__ __forceinline__ bool expanders_past_their_wait(CArgs &a, uint64_t gro
     for (;;) {
         const uint32_t c = lane < kCtlShards ? ld_sc1(a.ctl + lane * kCtlStride) : 0u;
         if ((uint64_t)wave_sum_u32(c & 0xFFFFu) >= groups) return wave_sum_u32(c >> 16) != 0u;     // (a shard has at most 1024 groups)
-        if (wall_clock64() > deadline) { if (lane == 0) st_sc1(a.status, 1u); return false; }
+        if (wall_clock64() > deadline) { if (lane == 0) report_gave_up(a); return false; }
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -811,7 +816,12 @@ __device__ __forceinline__ void store_list(CArgs &a, uint32_t *stage32, uint64_t
 // the step -> four IDs per lane and store.
 // (`step_uses_list16` must agree between the tile that writes and the expander that reads: both see the count word.)
 __device__ __forceinline__ bool step_uses_list16(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
+#ifdef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
+    (void)a; (void)cnt; (void)rpl_log2;
+    return false;
+#else
     return a.lists != nullptr && cnt > (uint32_t)a.list16_min[rpl_log2 >= 4u ? 1 : 0];
+#endif
 }
 // the steps of a group that have a 128-byte slot to fetch (`cw` = a step's count word)
 __device__ __forceinline__ bool step_has_slot(CArgs &a, uint32_t cw) {
@@ -1303,9 +1313,13 @@ __device__ __forceinline__ uint32_t leader_prefetch_with(CArgs &a, FusedShared &
     typedef __attribute__((address_space(1))) const void global_cvoid;
     typedef __attribute__((address_space(3))) void lds_void;
     mask = 0;
-    const uint64_t nonempty = __ballot(step_has_slot(a, c));        // (a group that is its leader's alone has no step with a 16-bit list)
+    // steps with a 128-byte slot to fetch (a solo group may well hold steps with 16-bit lists: up to kSoloIds matches, a list
+    // from list16_min + 1 on -- those have no slot).  The packed order is taken exactly when expand_range's sparse branch
+    // will run: at most 16 NON-EMPTY steps, whichever form they left.
+    const uint64_t nonempty = __ballot(step_has_slot(a, c));
+    const uint64_t any_match = __ballot((c & kCountMask) != 0u);
     const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
-    if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(nonempty) <= (int)(kGroupSteps / kWaves)) {
+    if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(any_match) <= (int)(kGroupSteps / kWaves)) {
         uint32_t k = 0;
         for (uint64_t rest = nonempty; rest; rest &= rest - 1, k++) {     // uniform
             const uint32_t st = (uint32_t)__builtin_ctzll(rest);
@@ -1509,7 +1523,7 @@ __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_
         const uint32_t sum = wave_sum_u32(cw & kCountMask);
         if (lane == 0 && g % kSuperGroups == kSuperGroups - 1) st_sc1(a.ssum + g / kSuperGroups, tag | (own_super + (uint64_t)sum));
     } else if (recovery || final_word) {
-        if (lane == 0) st_sc1(a.status, 1u);                        // something never arrived: reported, never silent
+        if (lane == 0) report_gave_up(a);                        // something never arrived: reported, never silent
     } else {
         if (lane == 0) st_sc1(a.deferred + g, (a.epoch << kEpochShift) | (sum_out ? 3u : 1u));
         drain_stores();                                             // ... in memory before this leader says it is past its wait
@@ -1549,7 +1563,7 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
             if (alive && lane == 0) st_sc1(a.gsum + gg, tag | (uint64_t)sum);
         }
     }
-    if (!alive && lane == 0) st_sc1(a.status, 1u);                  // a scan tile never arrived: reported, never silent
+    if (!alive && lane == 0) report_gave_up(a);                  // a scan tile never arrived: reported, never silent
     drain_stores();
     // ... and the supergroup words still missing (every group sum is out now)
 #pragma unroll 1
@@ -1584,7 +1598,7 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
                 known = known && word_valid(a, w);
                 front += w & kWordMask;
             }
-            if (!__all(known)) { if (lane == 0) st_sc1(a.status, 1u); continue; }       // (cannot be: pass 1 saw to both)
+            if (!__all(known)) { if (lane == 0) report_gave_up(a); continue; }       // (cannot be: pass 1 saw to both)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: the payload loads stay behind the looks
             const uint32_t my_cnt = g * kGroupSteps + lane < ex.steps ? (cw & kCountMask) : 0u;
             OutRing r;

@@ -166,6 +166,57 @@ __global__ __launch_bounds__(256) void merge_slots_kernel(const uint32_t *slots,
     }
 }
 
+// ---- all-gatherv payload in compact form ---------------------------------------------------------------
+// A shard's ascending ID list is sent as the LOW 16 BITS of every row number (relative to the shard's first row) plus,
+// per 65 536-row group of the shard, the position in the list where the group's rows begin: 2 bytes per match + 4 bytes
+// per group instead of 4 bytes per match -- the xGMI links carry half the bytes for any answer denser than two matches per
+// 64 K rows (engine/mpi/executeEngine-mpi.c:765 ships `int`s; the receiving GPU rebuilds exactly those).  The sender decides
+// (header word 3) from its own count; the receiver sees the same header through the sizes all-gather (mpi:753).
+//   wire = [u32 goff[groups + 1], padded to 16 bytes][u16 low[n]]        goff[g] = first entry with row >= g * 65536, goff[groups] = n
+constexpr uint32_t kWireGroupRows = 1u << 16;
+constexpr uint64_t kWireHeaderWords = 4;                            // u64 per rank in the sizes all-gather: reported count, rows, id_base, format
+
+__host__ __device__ inline uint64_t wire_groups(uint64_t n_rows) { return (n_rows + kWireGroupRows - 1) / kWireGroupRows; }
+__host__ __device__ inline uint64_t wire_goff_bytes(uint64_t n_rows) { return ((wire_groups(n_rows) + 1) * 4 + 15) & ~15ull; }
+__host__ __device__ inline uint64_t wire_bytes(uint64_t n_rows, uint64_t n) { return wire_goff_bytes(n_rows) + ((n * 2 + 3) & ~3ull); }
+__host__ __device__ inline bool wire_pays(uint64_t n_rows, uint64_t n) { return wire_bytes(n_rows, n) < n * 4; }
+
+// slot = [u64 reported count][u64][u32 IDs ...] as the filter left it; hdr = this rank's 4 words of the sizes all-gather
+__global__ __launch_bounds__(256) void wire_pack_kernel(const uint32_t *slot, uint64_t cap, uint64_t n_rows, uint32_t id_base, int enabled,
+                                                        uint64_t *hdr, uint8_t *wire) {
+    const uint64_t reported = *(const uint64_t *)slot;
+    const uint64_t n = reported < cap ? reported : cap;            // a slot that overflowed holds (and sends) `cap` IDs
+    const bool compact = enabled && wire_pays(n_rows, n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = reported; hdr[1] = n_rows; hdr[2] = id_base; hdr[3] = compact ? 1u : 0u; }
+    if (!compact) return;
+    const uint32_t *ids = slot + kSlotHeaderWords;
+    uint32_t *goff = (uint32_t *)wire;
+    uint16_t *low = (uint16_t *)(wire + wire_goff_bytes(n_rows));
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = tid; i < n; i += nthreads) low[i] = (uint16_t)(ids[i] - id_base);
+    const uint64_t groups = wire_groups(n_rows);
+    for (uint64_t g = tid; g <= groups; g += nthreads) {           // lower bound of the group's first row in the ascending list
+        const uint64_t first = g * kWireGroupRows;
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if ((uint64_t)(ids[mid] - id_base) < first) lo = mid + 1; else hi = mid;
+        }
+        goff[g] = (uint32_t)lo;
+    }
+}
+
+// out[i] = id_base + g * 65536 + low[i] for the entries i of group g (a workgroup walks groups, its threads a group's entries)
+__global__ __launch_bounds__(256) void wire_expand_kernel(const uint8_t *wire, uint64_t n_rows, uint32_t id_base, uint32_t *out) {
+    const uint32_t *goff = (const uint32_t *)wire;
+    const uint16_t *low = (const uint16_t *)(wire + wire_goff_bytes(n_rows));
+    const uint64_t groups = wire_groups(n_rows);
+    for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const uint32_t b = goff[g], e = goff[g + 1], base = id_base + (uint32_t)(g * kWireGroupRows);
+        for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) out[i] = base + (uint32_t)low[i];
+    }
+}
+
 // ---- DELETE support: keep-list gather ------------------------------------------------------------
 // dst[i] = src[keep[i]]; keep is ascending, so a wave's reads fall into a few neighbouring lines.
 template <typename T>
@@ -198,6 +249,22 @@ __global__ __launch_bounds__(256) void project_kernel(const T *__restrict__ col,
     if (n > capacity) n = capacity;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = col[ids[i] - id_base];
+}
+
+// checksums of an ID list: out[0] += sum ids[i], out[1] += sum ids[i] * (2 i + 1)   (mod 2^64; out zeroed by the caller)
+__global__ __launch_bounds__(256) void ids_checksum_kernel(const uint32_t *__restrict__ ids, uint64_t n, uint64_t *out) {
+    uint64_t s0 = 0, s1 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = ids[i];
+        s0 += v;
+        s1 += v * (2ull * i + 1ull);
+    }
+    s0 = wave_sum_u64(s0);
+    s1 = wave_sum_u64(s1);
+    if ((threadIdx.x & 63) == 0 && (s0 | s1)) {
+        atomicAdd((unsigned long long *)&out[0], (unsigned long long)s0);
+        atomicAdd((unsigned long long *)&out[1], (unsigned long long)s1);
+    }
 }
 
 // rank-order compaction of [count | ids] slots together with their parallel key slots
@@ -260,6 +327,18 @@ uint64_t now_ns() {
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
+// Tuning switches (A/B runs of scripts/) exist in development builds only (-DPQPS_TUNING: `make libpqps_hip_dev.so`); the
+// default build reads the deployment settings and the switches the test-suite forces kernel variants with (scripts/README.md
+// lists which is which).
+inline const char *tuning_env(const char *name) {
+#ifdef PQPS_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -299,11 +378,16 @@ struct pqps_ctx {
     uint64_t hand_groups;       // capacity
     uint32_t epoch;             // of the last ID query; 1 .. 65535, then the tagged arrays are zeroed and it starts over
     int parity;                 // ctl half the next ID query uses
-    bool needs_reset;           // a launch failed or a wait ran out: tagged words, ctl and epoch start over before the next ID query
+    std::atomic<bool> needs_reset;   // a launch failed or a wait ran out: tagged words, ctl and epoch start over before the next ID query
+                                // (set by whoever awaits the failed launch, possibly while another thread issues on this context)
     uint64_t *base_slot;        // gather: first output slot of the running query
     uint64_t *partials;         // workgroup totals of the scan (COUNT / FLAGS modes)
-    uint32_t *status_host;      // mapped host word: set by a kernel whose recovery pass gave up
-    uint32_t *status_dev;       // its device address
+    uint32_t *status_host;      // [kStatusWords] mapped host words: a launch whose bounded waits ran out stores its epoch in word epoch % kStatusWords
+    uint32_t *status_dev;       // their device address
+    uint64_t *check_dev;        // [2] pqps_ids_checksum
+    // per-context overrides of the launch parameters (pqps_ctx_set_option: A/B runs inside ONE process, where the physical
+    // placement of the table is the same for every variant); -1 = the default
+    long opt_list16, opt_list16_min, opt_list16_min_u8, opt_expand_lag, opt_sum_lag, opt_tune;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     // optional per-launch timing (bench.py roofline)
@@ -369,7 +453,7 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     HIP_TRY(hipDeviceSynchronize());
     ctx->parity = 0;
     ctx->epoch = first_epoch();
-    ctx->needs_reset = false;
+    ctx->needs_reset.store(false);
     return PQPS_OK;
 }
 
@@ -400,18 +484,37 @@ int reset_handoff(pqps_ctx *ctx, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(ctx->ctl, 0, 2 * kCtlWords * sizeof(uint32_t), s));
     ctx->parity = 0;
     ctx->epoch = 0;
-    ctx->needs_reset = false;
     return PQPS_OK;
 }
 
-// The sticky status word (mapped host memory) is reported ONCE: it is cleared and the hand-off words start over, so
-// the context stays usable after the failed query (include/executeEngine-hip.h promises that to the engine's callers).
+// The status words (mapped host memory) name the launches that gave up, by epoch.  A failure is reported ONCE -- its word
+// is cleared and the hand-off words start over before the next ID query -- so the context stays usable after the failed
+// query (include/executeEngine-hip.h promises that to the engine's callers).
+// take_status: any launch of the context (callers that have waited for everything on it: pqps_ctx_sync, the syncs of a
+// query stream / an exchange).  take_status_of: the launches with epochs lo .. hi only (pqps_qstream_wait: the slot's own
+// launches -- another slot's query may have run on the same lane and is reported to whoever awaits THAT slot).
 int take_status(pqps_ctx *ctx, const char *who) {
-    const uint32_t st = *(volatile uint32_t *)ctx->status_host;
+    uint32_t st = 0;
+    for (uint32_t w = 0; w < kStatusWords; w++) {
+        const uint32_t v = ((volatile uint32_t *)ctx->status_host)[w];
+        if (v) { st = v; ((volatile uint32_t *)ctx->status_host)[w] = 0; }
+    }
     if (st == 0) return PQPS_OK;
-    *(volatile uint32_t *)ctx->status_host = 0;
-    ctx->needs_reset = true;
-    return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (status %u): results of this %s are incomplete", st, who);
+    ctx->needs_reset.store(true);
+    return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (epoch %u): results of this %s are incomplete", st, who);
+}
+
+int take_status_of(pqps_ctx *ctx, uint32_t lo, uint32_t hi, const char *who) {
+    if (lo == 0 && hi == 0) return PQPS_OK;                      // no ID launch (COUNT, an empty table)
+    if (hi < lo || hi - lo >= kStatusWords) return take_status(ctx, who);      // epochs wrapped or started over in between: any
+    uint32_t st = 0;
+    for (uint32_t e = lo; e <= hi; e++) {
+        volatile uint32_t *w = (volatile uint32_t *)ctx->status_host + (e & (kStatusWords - 1u));
+        if (*w == e) { st = e; *w = 0; }
+    }
+    if (st == 0) return PQPS_OK;
+    ctx->needs_reset.store(true);
+    return fail(PQPS_EHIP, "an ID-output launch gave up waiting for its scan tiles (epoch %u): results of this %s are incomplete", st, who);
 }
 
 int check_pred(const pqps_column *cols, uint32_t n_cols, const pqps_predicate *pred) {
@@ -559,11 +662,11 @@ eval_fn pick_eval(const pqps_column *cols, uint32_t n_cols, const pqps_predicate
     if (n_cols >= 1 && n_cols <= 3 && pred->n_leaves >= 1 && pred->n_leaves <= PQPS_TT_LEAVES) {
         const uint32_t w0 = cols[0].width, w1 = n_cols > 1 ? cols[1].width : 0, w2 = n_cols > 2 ? cols[2].width : 0;
         // several steps per iteration only where chain_steps() says so (a lone 1-byte column)
-        static const char *force = getenv("PQPS_CHAIN_MULTI");
+        static const char *force = tuning_env("PQPS_CHAIN_MULTI");
         const bool multi = force ? atoi(force) != 0 : true;
         // one comparison on one column (EV 1), or -- where measured faster -- a chain over narrow columns (EV 2), on the
         // vector unit: see RawStep::one_leaf / valu_leaf
-        static const char *valu_env = getenv("PQPS_VALU_CHAIN");                 // tuning runs: 0 / 1 = ballots / vector unit for every eligible chain
+        static const char *valu_env = tuning_env("PQPS_VALU_CHAIN");                 // tuning runs: 0 / 1 = ballots / vector unit for every eligible chain
         const bool one = pred->n_leaves == 1 && n_cols == 1;
         const bool valu = valu_chain_shape((int)w0, (int)w1, (int)w2) && (valu_env ? atoi(valu_env) != 0 : valu_chain_default(w0, w1, w2, MODE, n_rows));
         const int vc = a.chain == 0 ? 0 : (one ? 1 : (valu ? 2 : 0));
@@ -595,9 +698,9 @@ uint32_t eval_grid(pqps_ctx *ctx, uint64_t steps, bool streaming, uint32_t steps
     const uint64_t per_wg = (uint64_t)kWaves * (steps_per_iter ? steps_per_iter : 1);   // steps one workgroup takes per iteration
     const uint64_t want = (steps + per_wg - 1) / per_wg;
     uint64_t cap = streaming ? (uint64_t)ctx->compute_units * kEvalBlocksPerCUMax : want * 2 / 3 + 1;
-    static const char *env = getenv("PQPS_K1_BLOCKS_PER_CU");    // tuning runs
+    static const char *env = tuning_env("PQPS_K1_BLOCKS_PER_CU");    // tuning runs
     if (env && atoi(env) >= 1 && atoi(env) <= kEvalBlocksPerCUMax) cap = (uint64_t)ctx->compute_units * (uint64_t)atoi(env);
-    static const char *it_env = getenv("PQPS_K1_ITERS");          // tuning runs: iterations per wave
+    static const char *it_env = tuning_env("PQPS_K1_ITERS");          // tuning runs: iterations per wave
     if (it_env && atof(it_env) > 0) {
         cap = (uint64_t)((double)want / atof(it_env)) + 1;
         const uint64_t hard = (uint64_t)ctx->compute_units * kEvalBlocksPerCUMax;
@@ -690,7 +793,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         if (done) HIP_TRY(hipEventRecord(done, s));
         return PQPS_OK;
     }
-    if (ctx->needs_reset) { rc = reset_handoff(ctx, s); if (rc) return rc; }
+    if (ctx->needs_reset.exchange(false)) { rc = reset_handoff(ctx, s); if (rc) { ctx->needs_reset.store(true); return rc; } }
     if (ctx->epoch >= 0xFFFFu) {                                 // the tags are about to repeat: start over from "never written"
         rc = zero_tagged_words(ctx, s);
         if (rc) return rc;
@@ -704,31 +807,40 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.ctl = ctx->ctl + half * kCtlWords;
     a.zctl = ctx->ctl + (half ^ 1) * kCtlWords;
     a.base_slot = ctx->base_slot;
-    a.lists = gather ? nullptr : ensure_lists(ctx, steps);
+    // The list area serves launches whose expanders run BEHIND the last tile (below kInterleaveFromGroups groups): there the
+    // expansion is the launch's tail and a copy is what it should be (`risk_level > 1` at 100 M rows 161 -> 130 us, `> 2`
+    // 101 -> 91; few-percent answers level).  Among the tiles -- 268 M rows and more -- the expansion hides under the scan
+    // whatever form the matches were left in, and the lists only add traffic and a longer tile: same-process A/B at 1 G rows
+    // on two boxes, lists / none: S1 500 / 493 and 501 / 484 us, Q_A 800 / 753 and 747 / 743, Q_B 1080 / 999 and 987 / 967,
+    // `risk_level > 2` 1051 / 929 and 921 / 893, `> 1` 1475 / 1254 (round 3 had compared processes, whose tables lie elsewhere).
+    const bool lists_wanted = ctx->opt_list16 >= 0 ? ctx->opt_list16 != 0 : groups < kInterleaveFromGroups;
+    a.lists = (gather || !lists_wanted) ? nullptr : ensure_lists(ctx, steps);
     {
         // Measured at 100 M rows (S1 / Q_A / Q_B / risk_level > 2, us per query): from 103 matches on 58.7 / 91.7 / 108.6 / 91.7, from 33
         // 57.8 / 90.6 / 104.6 / 91.8, from 9 58.3 / 88.8 / 104.4 / 91.5, every non-empty step 60.7 / 88.7 / 104.2 / 91.6: the 10-bit list
         // inside the step's 128-byte slot stays for the steps of a sparse answer (their slots are fetched while the leader
         // still waits for the sums in front).  1-byte columns: their tiles have no instruction slots to spare (a lone u8
         // column with 7 % matches: 47.5 us with bit masks, 56 - 58 with lists).
-        static const uint32_t from = [] { const char *e = getenv("PQPS_LIST16_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 8u; }();
-        static const uint32_t from_u8 = [] { const char *e = getenv("PQPS_LIST16_MIN_U8"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; }();
-        a.list16_min[0] = (uint16_t)(from < 1024u ? from : 1024u);
-        a.list16_min[1] = (uint16_t)(from_u8 < 1024u ? from_u8 : 1024u);
+        static const uint32_t from = [] { const char *e = tuning_env("PQPS_LIST16_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 8u; }();
+        static const uint32_t from_u8 = [] { const char *e = tuning_env("PQPS_LIST16_MIN_U8"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; }();
+        const uint32_t f0 = ctx->opt_list16_min >= 0 ? (uint32_t)ctx->opt_list16_min : from;
+        const uint32_t f1 = ctx->opt_list16_min_u8 >= 0 ? (uint32_t)ctx->opt_list16_min_u8 : from_u8;
+        a.list16_min[0] = (uint16_t)(f0 < 1024u ? f0 : 1024u);
+        a.list16_min[1] = (uint16_t)(f1 < 1024u ? f1 : 1024u);
     }
     a.status = ctx->status_dev;
     a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
     a.id_base = id_base;
     a.accumulate = gather ? 1u : 0u;
     const uint32_t tiles_per_group = (uint32_t)kGroupSteps / ((uint32_t)kWaves * (a.steps_per_iter ? a.steps_per_iter : 1u));
-    a.lag = gather ? 0x7FFFFFFFu : expand_lag(ctx, tiles_per_group, groups);   // (a looping gather grid has all its expanders behind its tiles)
+    a.lag = gather ? 0x7FFFFFFFu : (ctx->opt_expand_lag >= 0 ? (uint32_t)ctx->opt_expand_lag : expand_lag(ctx, tiles_per_group, groups));   // (a looping gather grid has all its expanders behind its tiles)
     a.grid_groups = (uint32_t)groups;
-    a.sum_lag = expand_sum_lag(ctx, tiles_per_group);
+    a.sum_lag = ctx->opt_sum_lag >= 0 ? (uint32_t)ctx->opt_sum_lag : expand_sum_lag(ctx, tiles_per_group);
     if (a.sum_lag == 0) a.sum_lag = 1;                           // a tile never sums up its own group
     if (a.sum_lag > 0x3FFFFFFFu) a.sum_lag = 0x3FFFFFFFu;         // (2 * sum_lag is computed in 32 bits)
     a.spin_limit = expand_spin_limit();
-    static const uint32_t tune = [] { const char *e = getenv("PQPS_TUNE"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
-    a.tune = tune;
+    static const uint32_t tune = [] { const char *e = tuning_env("PQPS_TUNE"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+    a.tune = ctx->opt_tune >= 0 ? (uint32_t)ctx->opt_tune : tune;
     // gather: [tiles of `groups` groups][four expander workgroups per group]; scan: quads of tiles with their expander slot, then the trailing groups
     const uint64_t main_blocks = gather ? groups * tiles_per_group : ((groups + 3) / 4) * (4ull * tiles_per_group + 1);
     const uint64_t lag = gather ? 4 * groups : trailing_groups((uint32_t)groups, a.lag);
@@ -760,7 +872,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {
-            ctx->needs_reset = true;
+            ctx->needs_reset.store(true);
             return fail(PQPS_EHIP, "filter launch failed: %s", hipGetErrorString(le));
         }
     }
@@ -831,7 +943,9 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->lists = nullptr; ctx->list_steps = 0; ctx->lists_refused = false;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
-    ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset = false;
+    ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset.store(false);
+    ctx->check_dev = nullptr;
+    ctx->opt_list16 = ctx->opt_list16_min = ctx->opt_list16_min_u8 = ctx->opt_expand_lag = ctx->opt_sum_lag = ctx->opt_tune = -1;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
@@ -839,7 +953,7 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->ev_start = ctx->ev_eval = ctx->ev_stop = nullptr;
     ctx->stop_is_eval = nullptr;
     hipError_t se;
-    const char *prio = getenv("PQPS_STREAM_PRIORITY");           // experiments: the context's own stream at a given priority
+    const char *prio = tuning_env("PQPS_STREAM_PRIORITY");           // experiments: the context's own stream at a given priority
     if (prio || lane) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -852,8 +966,8 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     }
     if (se != hipSuccess) { delete ctx; return fail(PQPS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     // sticky status word in mapped host memory: a kernel whose recovery pass gave up sets it, pqps_ctx_sync reports it
-    se = hipHostMalloc((void **)&ctx->status_host, 64, hipHostMallocMapped);
-    if (se == hipSuccess) { *ctx->status_host = 0; se = hipHostGetDevicePointer((void **)&ctx->status_dev, ctx->status_host, 0); }
+    se = hipHostMalloc((void **)&ctx->status_host, kStatusWords * sizeof(uint32_t), hipHostMallocMapped);
+    if (se == hipSuccess) { memset(ctx->status_host, 0, kStatusWords * sizeof(uint32_t)); se = hipHostGetDevicePointer((void **)&ctx->status_dev, ctx->status_host, 0); }
     if (se != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return fail(PQPS_EHIP, "status word: %s", hipGetErrorString(se)); }
     hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(1), 0, ctx->stream);
     se = hipGetLastError();
@@ -903,6 +1017,7 @@ void pqps_ctx_destroy(pqps_ctx *ctx) {
         delete[] ctx->stop_is_eval;
     }
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+    if (ctx->check_dev) (void)hipFree(ctx->check_dev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -943,6 +1058,19 @@ int pqps_ctx_kernel_time(pqps_ctx *ctx, double *eval_ms, double *total_ms, int *
     *launches = ctx->timed;
     ctx->timed = 0;
     return PQPS_OK;
+}
+
+// Launch parameters of this context's ID queries, overriding the defaults (value < 0: back to the default).  For A/B runs
+// inside one process (scripts/ab_libs.py) and for tests that force a kernel variant on one context only.
+int pqps_ctx_set_option(pqps_ctx *ctx, const char *name, long value) {
+    if (!ctx || !name) return fail(PQPS_EINVAL, "NULL argument");
+    struct { const char *name; long *slot; } opts[] = {
+        {"list16", &ctx->opt_list16}, {"list16_min", &ctx->opt_list16_min}, {"list16_min_u8", &ctx->opt_list16_min_u8},
+        {"expand_lag", &ctx->opt_expand_lag}, {"sum_lag", &ctx->opt_sum_lag}, {"tune", &ctx->opt_tune},
+    };
+    for (auto &o : opts)
+        if (strcmp(o.name, name) == 0) { *o.slot = value < 0 ? -1 : value; return PQPS_OK; }
+    return fail(PQPS_EINVAL, "unknown option '%s'", name);
 }
 
 int pqps_ctx_sync(pqps_ctx *ctx, void *stream) {
@@ -1454,6 +1582,7 @@ int load_rccl(const char *path, RcclApi *api) {
 
 enum : uint8_t { kSlotIdle = 0, kSlotSizesInFlight = 1, kSlotDone = 2, kSlotCount = 3 };
 constexpr uint32_t kExchangeLanes = 2;      // scans in flight, each whole on a stream of its own (as in pqps_qstream)
+constexpr int kRcclUint8 = 1;               // ncclUint8: the compact payload travels as bytes
 
 }  // namespace
 
@@ -1468,14 +1597,20 @@ struct pqps_exchange {
     uint64_t *caps;                  // [world] every rank's `cap` (they may differ: shards differ by a row)
     hipStream_t stream;              // the exchange stream
     uint32_t *local;                 // [ring][stride]   [u64 count][u64 reserved][IDs] of this rank
-    uint64_t *sizes_dev;             // [ring][world]    gathered counts
-    uint64_t *sizes_host;            // [ring][world]    ... on the host (pinned)
+    uint64_t *hdr_dev;               // [ring][4]        this rank's words of the sizes all-gather: reported count, rows, id_base, format
+    uint64_t *sizes_dev;             // [ring][world][4] gathered headers
+    uint64_t *sizes_host;            // [ring][world][4] ... on the host (pinned)
+    uint8_t **wire_out;              // [ring]           this rank's payload in compact form (wire_pack_kernel), grown to the rows of a call
+    uint64_t *wire_out_cap;
+    uint8_t **wire_in;               // [ring]           the peers' compact payloads as received, grown to what a query needs
+    uint64_t *wire_in_cap;
     uint32_t **merged;               // [ring]           the gathered list, grown to what a query needs
     uint64_t *merged_cap;
     uint64_t *totals;                // [ring][2]        device: COUNT(*) result
     uint64_t *totals_host;           // [ring][2]        merged / reported IDs of a SELECT slot
     hipEvent_t *scan_done, *k1_done, *sizes_done, *merge_done;
     hipEvent_t joined;               // what the caller's stream held when the queries began
+    hipEvent_t fence;                // pqps_exchange_sync: the end of a stream, awaited with a bound
     bool ordered;                    // the lanes already wait for the caller's stream
     pqps_ctx **child;                // [kExchangeLanes] scratch + HIP stream of the scans in flight (see pqps_qstream)
     uint8_t *state;
@@ -1483,6 +1618,10 @@ struct pqps_exchange {
     uint64_t calls;
     uint64_t wait_ns;                // host time spent waiting for a slot to come free
     uint64_t sizes_wait_ns;          // host time spent waiting for the sizes of a query
+    bool compact;                    // answers that gain from it travel in compact form (PQPS_EXCHANGE_COMPACT=0: always u32)
+    uint64_t wire_bytes_in, u32_bytes_in;    // payload this rank has received: as it travelled / as u32 IDs would have
+    double timeout_s;                // bound of every host wait of the exchange (PQPS_EXCHANGE_TIMEOUT_S, default 30; 0: none)
+    bool dead;                       // a wait ran out (or a rank could not receive): the communicator is aborted, every call fails
 };
 
 int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id) {
@@ -1497,21 +1636,29 @@ int pqps_exchange_unique_id(const char *rccl_library, pqps_rccl_id *id) {
 
 int pqps_exchange_destroy(pqps_exchange *x) {
     if (!x) return PQPS_OK;
-    if (x->stream) (void)hipStreamSynchronize(x->stream);
-    if (x->comm) (void)x->rccl.CommDestroy(x->comm);
+    (void)hipSetDevice(x->ctx->device);
+    // a dead exchange may still have a collective of the aborted communicator in its stream: no unbounded wait for it
+    if (x->stream && !x->dead) (void)hipStreamSynchronize(x->stream);
+    if (x->comm) { if (x->dead && x->rccl.CommAbort) (void)x->rccl.CommAbort(x->comm); else (void)x->rccl.CommDestroy(x->comm); x->comm = nullptr; }
+    if (x->stream && x->dead) (void)hipStreamSynchronize(x->stream);     // (the abort has ended what was stuck)
     for (uint32_t i = 0; i < x->ring; i++) {
         if (x->scan_done && x->scan_done[i]) (void)hipEventDestroy(x->scan_done[i]);
         if (x->k1_done && x->k1_done[i]) (void)hipEventDestroy(x->k1_done[i]);
         if (x->sizes_done && x->sizes_done[i]) (void)hipEventDestroy(x->sizes_done[i]);
         if (x->merge_done && x->merge_done[i]) (void)hipEventDestroy(x->merge_done[i]);
         if (x->merged && x->merged[i]) (void)hipFree(x->merged[i]);
+        if (x->wire_out && x->wire_out[i]) (void)hipFree(x->wire_out[i]);
+        if (x->wire_in && x->wire_in[i]) (void)hipFree(x->wire_in[i]);
     }
     for (uint32_t i = 0; i < kExchangeLanes; i++)
         if (x->child && x->child[i]) { (void)hipStreamSynchronize(x->child[i]->stream); pqps_ctx_destroy(x->child[i]); }
     if (x->joined) (void)hipEventDestroy(x->joined);
+    if (x->fence) (void)hipEventDestroy(x->fence);
     delete[] x->scan_done; delete[] x->k1_done; delete[] x->sizes_done; delete[] x->merge_done; delete[] x->child;
     delete[] x->state; delete[] x->issued; delete[] x->merged; delete[] x->merged_cap; delete[] x->totals_host; delete[] x->caps;
+    delete[] x->wire_out; delete[] x->wire_out_cap; delete[] x->wire_in; delete[] x->wire_in_cap;
     if (x->local) (void)hipFree(x->local);
+    if (x->hdr_dev) (void)hipFree(x->hdr_dev);
     if (x->sizes_dev) (void)hipFree(x->sizes_dev);
     if (x->sizes_host) (void)hipHostFree(x->sizes_host);
     if (x->totals) (void)hipFree(x->totals);
@@ -1531,6 +1678,8 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     x->ctx = ctx; x->world = world; x->rank = rank; x->ring = ring;
     x->cap = (slot_capacity + 1) & ~1ull;                      // keeps every slot 8-byte aligned
     x->stride = x->cap + kSlotHeaderWords;
+    { const char *e = getenv("PQPS_EXCHANGE_COMPACT"); x->compact = !e || atoi(e) != 0; }
+    { const char *e = getenv("PQPS_EXCHANGE_TIMEOUT_S"); x->timeout_s = e ? atof(e) : 30.0; if (x->timeout_s < 0) x->timeout_s = 0; }
     int rc = load_rccl(rccl_library, &x->rccl);
     if (rc) { pqps_exchange_destroy(x); return rc; }
 #define X_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { pqps_exchange_destroy(x); \
@@ -1538,18 +1687,23 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     X_TRY(hipSetDevice(ctx->device));
     X_TRY(hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking));
     X_TRY(hipMalloc((void **)&x->local, (size_t)ring * x->stride * 4));
-    X_TRY(hipMalloc((void **)&x->sizes_dev, (size_t)ring * world * sizeof(uint64_t)));
-    X_TRY(hipHostMalloc((void **)&x->sizes_host, (size_t)ring * world * sizeof(uint64_t), hipHostMallocDefault));
+    X_TRY(hipMalloc((void **)&x->hdr_dev, (size_t)ring * kWireHeaderWords * sizeof(uint64_t)));
+    X_TRY(hipMalloc((void **)&x->sizes_dev, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t)));
+    X_TRY(hipHostMalloc((void **)&x->sizes_host, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t), hipHostMallocDefault));
     X_TRY(hipMalloc((void **)&x->totals, (size_t)ring * 2 * sizeof(uint64_t)));
     X_TRY(hipMemset(x->local, 0, (size_t)ring * x->stride * 4));
+    X_TRY(hipMemset(x->hdr_dev, 0, (size_t)ring * kWireHeaderWords * sizeof(uint64_t)));
     X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
+    memset(x->sizes_host, 0, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t));
     x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->sizes_done = new hipEvent_t[ring]();
     x->merge_done = new hipEvent_t[ring]();
     x->child = new pqps_ctx *[kExchangeLanes](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
     X_TRY(hipEventCreateWithFlags(&x->joined, hipEventDisableTiming));
+    X_TRY(hipEventCreateWithFlags(&x->fence, hipEventDisableTiming));
     for (uint32_t i = 0; i < kExchangeLanes; i++)
         if (create_ctx(ctx->device, true, &x->child[i]) != PQPS_OK) { pqps_exchange_destroy(x); return PQPS_EHIP; }
     x->merged = new uint32_t *[ring](); x->merged_cap = new uint64_t[ring](); x->totals_host = new uint64_t[2 * (size_t)ring]();
+    x->wire_out = new uint8_t *[ring](); x->wire_out_cap = new uint64_t[ring](); x->wire_in = new uint8_t *[ring](); x->wire_in_cap = new uint64_t[ring]();
     x->caps = new uint64_t[world]();
     for (uint32_t i = 0; i < ring; i++) {
         X_TRY(hipEventCreateWithFlags(&x->scan_done[i], hipEventDisableTiming));
@@ -1565,101 +1719,145 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     return PQPS_OK;
 }
 
-int pqps_exchange_connect(pqps_exchange *x, const pqps_rccl_id *id) {
-    if (!x || !id) return fail(PQPS_EINVAL, "NULL argument");
-    if (x->comm) return fail(PQPS_EINVAL, "exchange is connected already");
-    (void)hipSetDevice(x->ctx->device);
-    int nrc = x->rccl.CommInitRank(&x->comm, (int)x->world, *id, (int)x->rank);
-    if (nrc) {
-        x->comm = nullptr;
-        return fail(PQPS_EHIP, "ncclCommInitRank(world %u, rank %u): %s", x->world, x->rank, x->rccl.GetErrorString(nrc));
-    }
-    // every rank's slot capacity, once: a rank whose own slot overflowed sends what it holds, and its peers
-    // have to size their receives the same way
-    x->caps[x->rank] = x->cap;
-    if (x->world > 1) {
-        uint64_t *mine = x->sizes_dev, *all = x->sizes_host;      // slot 0's buffers, not in use yet
-        HIP_TRY(hipMemcpyAsync(x->local, &x->cap, sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
-        nrc = x->rccl.AllGather(x->local, mine, 1, kRcclUint64, x->comm, x->stream);
-        if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
-        HIP_TRY(hipMemcpyAsync(all, mine, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
-        HIP_TRY(hipMemsetAsync(x->local, 0, sizeof(uint64_t), x->stream));
-        HIP_TRY(hipStreamSynchronize(x->stream));
-        for (uint32_t r = 0; r < x->world; r++) x->caps[r] = all[r];
-    }
-    return PQPS_OK;
-}
-
-int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world, uint32_t rank,
-                         uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
-    if (!id || !out) return fail(PQPS_EINVAL, "NULL argument");
-    pqps_exchange *x = nullptr;
-    int rc = pqps_exchange_prepare(ctx, rccl_library, world, rank, slot_capacity, ring, &x);
-    if (rc) return rc;
-    rc = pqps_exchange_connect(x, id);
-    if (rc) { pqps_exchange_destroy(x); return rc; }
-    *out = x;
-    return PQPS_OK;
-}
-
 }  // extern "C"
 
 namespace {
+
+// Every host wait of the exchange has a deadline.  A collective whose peer never arrives would otherwise hold the process
+// -- one that has touched the GPU and cannot be replaced -- for ever: on expiry the communicator is aborted (which ends the
+// peers' matching calls with an error, and whatever of this rank's is stuck in the stream), the exchange is marked dead
+// and every later call fails at once; the host falls back to its other exchange path (merge.py) or tears down.
+int exchange_died(pqps_exchange *x, const char *what) {
+    x->dead = true;
+    if (x->comm && x->rccl.CommAbort) { (void)x->rccl.CommAbort(x->comm); x->comm = nullptr; }
+    return fail(PQPS_ETIMEOUT, "exchange: %s did not finish within %.1f s (a peer is missing or stalled); communicator aborted", what, x->timeout_s);
+}
+
+int exchange_wait(pqps_exchange *x, hipEvent_t ev, const char *what) {
+    hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return PQPS_OK;
+    if (e != hipErrorNotReady) return fail(PQPS_EHIP, "exchange: %s: %s", what, hipGetErrorString(e));
+    if (x->timeout_s <= 0.0) { HIP_TRY(hipEventSynchronize(ev)); return PQPS_OK; }
+    const uint64_t deadline = now_ns() + (uint64_t)(x->timeout_s * 1e9);
+    uint32_t spins = 0;
+    for (;;) {
+        e = hipEventQuery(ev);
+        if (e == hipSuccess) return PQPS_OK;
+        if (e != hipErrorNotReady) return fail(PQPS_EHIP, "exchange: %s: %s", what, hipGetErrorString(e));
+        if (now_ns() > deadline) return exchange_died(x, what);
+        if (++spins > 2000) { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }      // (first ~100 us: a tight poll)
+    }
+}
+
+int exchange_wait_stream(pqps_exchange *x, hipStream_t s, const char *what) {
+    HIP_TRY(hipEventRecord(x->fence, s));
+    return exchange_wait(x, x->fence, what);
+}
+
+#define X_ALIVE(x) do { if ((x)->dead) return fail(PQPS_ETIMEOUT, "exchange is dead: an earlier wait ran out and the communicator was aborted"); } while (0)
+
+// room for `bytes` in one of the slot's wire buffers (the stream is idle for this slot: it was claimed)
+int wire_room(pqps_exchange *x, uint8_t **buf, uint64_t *cap, uint64_t bytes) {
+    if (bytes <= *cap) return PQPS_OK;
+    if (*buf) { int rc = exchange_wait_stream(x, x->stream, "growing a payload buffer"); if (rc) return rc; (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    const uint64_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc((void **)buf, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); *buf = nullptr; return fail(PQPS_ENOMEM, "payload buffer of %llu bytes: %s", (unsigned long long)want, hipGetErrorString(e)); }
+    *cap = want;
+    return PQPS_OK;
+}
 
 // Second half of a SELECT slot: the sizes are on the host, the payload moves.  Every rank comes through here
 // for the same slots in the same order (the order of its pqps_exchange_* calls).
 int exchange_payload(pqps_exchange *x, uint32_t slot) {
     if (x->state[slot] != kSlotSizesInFlight) return PQPS_OK;
     const uint64_t t0 = now_ns();
-    HIP_TRY(hipEventSynchronize(x->sizes_done[slot]));
+    int rc = exchange_wait(x, x->sizes_done[slot], "the sizes all-gather");
     x->sizes_wait_ns += now_ns() - t0;
-    const uint64_t *sizes = x->sizes_host + (uint64_t)slot * x->world;
-    uint64_t total = 0, reported = 0;
+    if (rc) return rc;
+    const uint64_t *hdr = x->sizes_host + (uint64_t)slot * x->world * kWireHeaderWords;      // [rank][count, rows, id_base, format]
+    auto held = [&](uint32_t r) { const uint64_t c = hdr[r * kWireHeaderWords]; return c < x->caps[r] ? c : x->caps[r]; };   // a rank whose own slot overflowed sends what it holds
+    uint64_t total = 0, reported = 0, staged = 0;
     for (uint32_t r = 0; r < x->world; r++) {                   // mpi:758-762
-        reported += sizes[r];
-        total += sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];  // a rank whose own slot overflowed sends what it holds
+        reported += hdr[r * kWireHeaderWords];
+        total += held(r);
+        if (r != x->rank && hdr[r * kWireHeaderWords + 3]) staged += (wire_bytes(hdr[r * kWireHeaderWords + 1], held(r)) + 15) & ~15ull;
     }
+    int grow = PQPS_OK;
     if (total > x->merged_cap[slot]) {
         // the consumer of this slot's previous result is done with it (the slot was handed out again)
-        HIP_TRY(hipStreamSynchronize(x->stream));
+        rc = exchange_wait_stream(x, x->stream, "growing the gathered list");
+        if (rc) return rc;
         (void)hipFree(x->merged[slot]);
         x->merged[slot] = nullptr;
         x->merged_cap[slot] = 0;
         uint64_t want = total + total / 4 + 4096;
         hipError_t e = hipMalloc((void **)&x->merged[slot], want * 4);
         if (e != hipSuccess) { (void)hipGetLastError(); want = total; e = hipMalloc((void **)&x->merged[slot], want * 4); }   // exactly what the payload needs
-        if (e != hipSuccess) {
-            // This rank cannot receive.  Its peers are about to enter (or already sit in) the same send / recv group and
-            // would wait for this rank's half of it forever: abort the communicator, which ends their calls with an
-            // error instead.  The exchange is dead after this; the caller tears it down.
-            x->merged[slot] = nullptr;
-            (void)hipGetLastError();
-            if (x->world > 1 && x->rccl.CommAbort && x->comm) { (void)x->rccl.CommAbort(x->comm); x->comm = nullptr; }
-            x->state[slot] = kSlotIdle;
-            return fail(PQPS_ENOMEM, "gathered ID list of %llu entries: %s (communicator aborted)", (unsigned long long)want, hipGetErrorString(e));
-        }
-        x->merged_cap[slot] = want;
+        if (e != hipSuccess) { x->merged[slot] = nullptr; (void)hipGetLastError(); grow = fail(PQPS_ENOMEM, "gathered ID list of %llu entries: %s", (unsigned long long)want, hipGetErrorString(e)); }
+        else x->merged_cap[slot] = want;
+    }
+    if (grow == PQPS_OK && staged) grow = wire_room(x, &x->wire_in[slot], &x->wire_in_cap[slot], staged);
+    if (grow != PQPS_OK) {
+        // This rank cannot receive.  Its peers are about to enter (or already sit in) the same send / recv group and
+        // would wait for this rank's half of it forever: abort the communicator, which ends their calls with an
+        // error instead.  The exchange is dead after this; the caller tears it down.
+        char why[256];
+        snprintf(why, sizeof why, "%s", g_err);
+        x->dead = true;
+        if (x->world > 1 && x->rccl.CommAbort && x->comm) { (void)x->rccl.CommAbort(x->comm); x->comm = nullptr; }
+        x->state[slot] = kSlotIdle;
+        return fail(PQPS_ENOMEM, "%s (communicator aborted)", why);
     }
     const uint32_t *mine = x->local + (uint64_t)slot * x->stride + kSlotHeaderWords;
     uint32_t *merged = x->merged[slot];
     int nrc = 0;
     // this rank's own part first: a failure here must not leave an opened group behind
     uint64_t displ = 0;
-    for (uint32_t r = 0; r < x->rank; r++) displ += sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];
-    const uint64_t own = sizes[x->rank] < x->cap ? sizes[x->rank] : x->cap;
+    for (uint32_t r = 0; r < x->rank; r++) displ += held(r);
+    const uint64_t own = held(x->rank);
+    const bool own_compact = hdr[x->rank * kWireHeaderWords + 3] != 0;
+    const uint64_t own_wire = own_compact ? wire_bytes(hdr[x->rank * kWireHeaderWords + 1], own) : own * 4;
     if (own) HIP_TRY(hipMemcpyAsync(merged + displ, mine, own * 4, hipMemcpyDeviceToDevice, x->stream));
     if (x->world > 1) nrc = x->rccl.GroupStart();
     displ = 0;
+    uint64_t at = 0;
     for (uint32_t r = 0; r < x->world && !nrc; r++) {           // mpi:765, as point-to-point pairs
-        const uint64_t k = sizes[r] < x->caps[r] ? sizes[r] : x->caps[r];
+        const uint64_t k = held(r);
         if (r != x->rank) {
-            if (own) nrc = x->rccl.Send(mine, (size_t)own, kRcclUint32, (int)r, x->comm, x->stream);
-            if (!nrc && k) nrc = x->rccl.Recv(merged + displ, (size_t)k, kRcclUint32, (int)r, x->comm, x->stream);
+            if (own) nrc = own_compact ? x->rccl.Send(x->wire_out[slot], (size_t)own_wire, kRcclUint8, (int)r, x->comm, x->stream)
+                                       : x->rccl.Send(mine, (size_t)own, kRcclUint32, (int)r, x->comm, x->stream);
+            if (!nrc && k) {
+                if (hdr[r * kWireHeaderWords + 3]) {
+                    const uint64_t wb = wire_bytes(hdr[r * kWireHeaderWords + 1], k);
+                    nrc = x->rccl.Recv(x->wire_in[slot] + at, (size_t)wb, kRcclUint8, (int)r, x->comm, x->stream);
+                    at += (wb + 15) & ~15ull;
+                    x->wire_bytes_in += wb;
+                } else {
+                    nrc = x->rccl.Recv(merged + displ, (size_t)k, kRcclUint32, (int)r, x->comm, x->stream);
+                    x->wire_bytes_in += k * 4;
+                }
+                x->u32_bytes_in += k * 4;
+            }
         }
         displ += k;
     }
     if (x->world > 1) { const int end = x->rccl.GroupEnd(); if (!nrc) nrc = end; }
     if (nrc) return fail(PQPS_EHIP, "ncclSend / ncclRecv: %s", x->rccl.GetErrorString(nrc));
+    // the peers' compact payloads become row IDs at their displacements
+    displ = 0; at = 0;
+    for (uint32_t r = 0; r < x->world; r++) {
+        const uint64_t k = held(r);
+        if (r != x->rank && k && hdr[r * kWireHeaderWords + 3]) {
+            const uint64_t rows = hdr[r * kWireHeaderWords + 1], groups = wire_groups(rows);
+            const uint64_t max_blocks = (uint64_t)x->ctx->compute_units * 8;
+            hipLaunchKernelGGL(wire_expand_kernel, dim3((uint32_t)(groups < max_blocks ? groups : max_blocks)), dim3(256), 0, x->stream,
+                               x->wire_in[slot] + at, rows, (uint32_t)hdr[r * kWireHeaderWords + 2], merged + displ);
+            HIP_TRY(hipGetLastError());
+            at += (wire_bytes(rows, k) + 15) & ~15ull;
+        }
+        displ += k;
+    }
     x->totals_host[2 * slot] = total;
     x->totals_host[2 * slot + 1] = reported;
     HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
@@ -1685,8 +1883,9 @@ int exchange_claim(pqps_exchange *x, uint32_t slot) {
     if (x->state[slot] == kSlotSizesInFlight) { int rc = exchange_payload(x, slot); if (rc) return rc; }
     if (x->state[slot] != kSlotIdle) {
         const uint64_t t0 = now_ns();
-        HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+        const int rc = exchange_wait(x, x->merge_done[slot], "the payload of an earlier query");
         x->wait_ns += now_ns() - t0;
+        if (rc) return rc;
     }
     x->state[slot] = kSlotIdle;
     return PQPS_OK;
@@ -1696,9 +1895,48 @@ int exchange_claim(pqps_exchange *x, uint32_t slot) {
 
 extern "C" {
 
+int pqps_exchange_connect(pqps_exchange *x, const pqps_rccl_id *id) {
+    if (!x || !id) return fail(PQPS_EINVAL, "NULL argument");
+    if (x->comm) return fail(PQPS_EINVAL, "exchange is connected already");
+    (void)hipSetDevice(x->ctx->device);
+    int nrc = x->rccl.CommInitRank(&x->comm, (int)x->world, *id, (int)x->rank);
+    if (nrc) {
+        x->comm = nullptr;
+        return fail(PQPS_EHIP, "ncclCommInitRank(world %u, rank %u): %s", x->world, x->rank, x->rccl.GetErrorString(nrc));
+    }
+    // every rank's slot capacity, once: a rank whose own slot overflowed sends what it holds, and its peers
+    // have to size their receives the same way
+    x->caps[x->rank] = x->cap;
+    if (x->world > 1) {
+        uint64_t *mine = x->sizes_dev, *all = x->sizes_host;      // slot 0's buffers, not in use yet
+        HIP_TRY(hipMemcpyAsync(x->local, &x->cap, sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
+        nrc = x->rccl.AllGather(x->local, mine, 1, kRcclUint64, x->comm, x->stream);
+        if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+        HIP_TRY(hipMemcpyAsync(all, mine, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipMemsetAsync(x->local, 0, sizeof(uint64_t), x->stream));
+        const int rc = exchange_wait_stream(x, x->stream, "the capacities all-gather");
+        if (rc) return rc;
+        for (uint32_t r = 0; r < x->world; r++) x->caps[r] = all[r];
+    }
+    return PQPS_OK;
+}
+
+int pqps_exchange_create(pqps_ctx *ctx, const char *rccl_library, const pqps_rccl_id *id, uint32_t world, uint32_t rank,
+                         uint64_t slot_capacity, uint32_t ring, pqps_exchange **out) {
+    if (!id || !out) return fail(PQPS_EINVAL, "NULL argument");
+    pqps_exchange *x = nullptr;
+    int rc = pqps_exchange_prepare(ctx, rccl_library, world, rank, slot_capacity, ring, &x);
+    if (rc) return rc;
+    rc = pqps_exchange_connect(x, id);
+    if (rc) { pqps_exchange_destroy(x); return rc; }
+    *out = x;
+    return PQPS_OK;
+}
+
 int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
                          const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    X_ALIVE(x);
     if (!x->comm) return fail(PQPS_EINVAL, "exchange is not connected");
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
     if (n_rows > 0xFFFFFFFFull || (uint64_t)id_base + n_rows > 0x100000000ull)
@@ -1719,8 +1957,14 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     rc = exchange_finish_older(x, x->calls + 1 - hold);
     if (rc) return rc;
     uint32_t *local = x->local + (uint64_t)slot * x->stride;
-    uint64_t *sizes_dev = x->sizes_dev + (uint64_t)slot * x->world;
-    uint64_t *sizes_host = x->sizes_host + (uint64_t)slot * x->world;
+    uint64_t *hdr_dev = x->hdr_dev + (uint64_t)slot * kWireHeaderWords;
+    uint64_t *sizes_dev = x->sizes_dev + (uint64_t)slot * x->world * kWireHeaderWords;
+    uint64_t *sizes_host = x->sizes_host + (uint64_t)slot * x->world * kWireHeaderWords;
+    const bool compact = x->compact && x->world > 1;
+    if (compact) {                                               // room for this call's payload in compact form
+        rc = wire_room(x, &x->wire_out[slot], &x->wire_out_cap[slot], wire_bytes(n_rows, x->cap < n_rows ? x->cap : n_rows));
+        if (rc) return rc;
+    }
     hipStream_t scan = pick_stream(x->ctx, scan_stream);
     EvalArgs a;
     fill_args(a, cols, n_cols, pred);
@@ -1750,14 +1994,23 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
         if (rc) return rc;
         HIP_TRY(hipStreamWaitEvent(x->stream, ev, 0));
     }
-    // sizes: mpi:753.  They are needed on the host (send / recv counts): an 8-byte-per-rank all-gather, then a
-    // copy into pinned memory behind it
+    // sizes: mpi:753.  They are needed on the host (send / recv counts): a 32-byte-per-rank all-gather -- reported count,
+    // the shard's rows and first row (what a receiver needs to rebuild IDs from the compact form), the form the sender
+    // chose -- then a copy into pinned memory behind it.  The pack kernel writes this rank's words (and the compact payload).
     if (x->world > 1) {
-        int nrc = x->rccl.AllGather(local, sizes_dev, 1, kRcclUint64, x->comm, x->stream);
+        const uint64_t n_max = x->cap < n_rows ? x->cap : n_rows;
+        uint64_t blocks = compact ? (n_max + 2047) / 2048 : 1;
+        const uint64_t max_blocks = (uint64_t)x->ctx->compute_units * 8;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks == 0) blocks = 1;
+        hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, x->stream, local, x->cap, n_rows, id_base, compact ? 1 : 0,
+                           hdr_dev, x->wire_out[slot]);
+        HIP_TRY(hipGetLastError());
+        int nrc = x->rccl.AllGather(hdr_dev, sizes_dev, kWireHeaderWords, kRcclUint64, x->comm, x->stream);
         if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
-        HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * kWireHeaderWords * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
     } else {
-        HIP_TRY(hipMemcpyAsync(sizes_host, local, sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipMemcpyAsync(sizes_host, local, sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));    // (words 1 - 3 stay 0: nobody to tell)
     }
     HIP_TRY(hipEventRecord(x->sizes_done[slot], x->stream));
     x->state[slot] = kSlotSizesInFlight;
@@ -1768,6 +2021,7 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
 int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows,
                         const pqps_predicate *pred, uint32_t slot, void *scan_stream) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    X_ALIVE(x);
     if (!x->comm) return fail(PQPS_EINVAL, "exchange is not connected");
     if (slot >= x->ring) return fail(PQPS_EINVAL, "slot %u >= ring %u", slot, x->ring);
     int rc = check_pred(cols, n_cols, pred);
@@ -1810,10 +2064,12 @@ int pqps_exchange_count(pqps_exchange *x, const pqps_column *cols, uint32_t n_co
 int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merged_dev, uint64_t *local_count,
                          uint64_t totals[2]) {
     if (!x || !totals) return fail(PQPS_EINVAL, "NULL argument");
+    X_ALIVE(x);
     if (slot >= x->ring || x->state[slot] == kSlotIdle) return fail(PQPS_EINVAL, "slot %u holds no result", slot);
     int rc = exchange_finish_older(x, x->issued[slot] + 1);       // up to and including this slot, in call order
     if (rc) return rc;
-    HIP_TRY(hipEventSynchronize(x->merge_done[slot]));
+    rc = exchange_wait(x, x->merge_done[slot], "the payload");
+    if (rc) return rc;
     if (x->state[slot] == kSlotCount) {
         HIP_TRY(hipMemcpy(totals, x->totals + 2 * (uint64_t)slot, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         if (local_count) HIP_TRY(hipMemcpy(local_count, x->local + (uint64_t)slot * x->stride, sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -1822,7 +2078,7 @@ int pqps_exchange_result(pqps_exchange *x, uint32_t slot, const uint32_t **merge
     }
     totals[0] = x->totals_host[2 * slot];
     totals[1] = x->totals_host[2 * slot + 1];
-    if (local_count) *local_count = x->sizes_host[(uint64_t)slot * x->world + x->rank];
+    if (local_count) *local_count = x->sizes_host[((uint64_t)slot * x->world + x->rank) * kWireHeaderWords];
     if (merged_dev) *merged_dev = x->merged[slot];
     if (totals[1] > totals[0])
         return fail(PQPS_EOVERFLOW, "exchange slot overflow: %llu IDs reported, capacity %llu per rank",
@@ -1837,16 +2093,55 @@ uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset) {
     return w;
 }
 
+// The compact wire form for a host that drives the exchange itself (merge.py over torch.distributed): the same two kernels.
+uint64_t pqps_wire_bytes(uint64_t n_rows, uint64_t n_ids) { return wire_bytes(n_rows, n_ids); }
+int pqps_wire_pays(uint64_t n_rows, uint64_t n_ids) { return wire_pays(n_rows, n_ids) ? 1 : 0; }
+
+int pqps_wire_pack(pqps_ctx *ctx, const uint32_t *slot, uint64_t capacity, uint64_t n_rows, uint32_t id_base, int enabled,
+                   uint64_t *header_dev, void *wire, void *stream) {
+    if (!ctx || !slot || !header_dev || (enabled && !wire)) return fail(PQPS_EINVAL, "NULL argument");
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t n_max = capacity < n_rows ? capacity : n_rows;
+    uint64_t blocks = enabled ? (n_max + 2047) / 2048 : 1;
+    const uint64_t max_blocks = (uint64_t)ctx->compute_units * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, slot, capacity, n_rows, id_base, enabled ? 1 : 0, header_dev, (uint8_t *)wire);
+    HIP_TRY(hipGetLastError());
+    return PQPS_OK;
+}
+
+int pqps_wire_expand(pqps_ctx *ctx, const void *wire, uint64_t n_rows, uint32_t id_base, uint32_t *out_ids, void *stream) {
+    if (!ctx || !wire || !out_ids) return fail(PQPS_EINVAL, "NULL argument");
+    hipStream_t s = pick_stream(ctx, stream);
+    const uint64_t groups = wire_groups(n_rows), max_blocks = (uint64_t)ctx->compute_units * 8;
+    if (groups == 0) return PQPS_OK;
+    hipLaunchKernelGGL(wire_expand_kernel, dim3((uint32_t)(groups < max_blocks ? groups : max_blocks)), dim3(256), 0, s, (const uint8_t *)wire, n_rows, id_base, out_ids);
+    HIP_TRY(hipGetLastError());
+    return PQPS_OK;
+}
+
+void pqps_exchange_wire_bytes(pqps_exchange *x, uint64_t out[2], int reset) {
+    if (!x || !out) return;
+    out[0] = x->wire_bytes_in;
+    out[1] = x->u32_bytes_in;
+    if (reset) x->wire_bytes_in = x->u32_bytes_in = 0;
+}
+
 int pqps_exchange_sync(pqps_exchange *x) {
     if (!x) return fail(PQPS_EINVAL, "exchange is NULL");
+    X_ALIVE(x);
     int rc = exchange_finish_older(x, x->calls + 1);
     if (rc) return rc;
+    (void)hipSetDevice(x->ctx->device);
     for (uint32_t i = 0; i < kExchangeLanes; i++) {
-        HIP_TRY(hipStreamSynchronize(x->child[i]->stream));
+        rc = exchange_wait_stream(x, x->child[i]->stream, "a scan lane");
+        if (rc) return rc;
         const int st = take_status(x->child[i], "exchange");
         if (st) return st;
     }
-    HIP_TRY(hipStreamSynchronize(x->stream));
+    rc = exchange_wait_stream(x, x->stream, "the exchange stream");
+    if (rc) return rc;
     x->ordered = false;                                          // the caller may have put new work on its stream meanwhile
     return PQPS_OK;
 }
@@ -1872,6 +2167,7 @@ struct pqps_qstream {
     hipEvent_t *done;                // [depth] the slots' own events
     hipEvent_t *ready;               // [depth] what to wait for: the slot's own event, or the timing recorder's stop event of its launch
     pqps_ctx **ran_on;               // [depth] lane (or the parent context) the slot's query ran on
+    uint32_t *ep_lo, *ep_hi;         // [depth] epochs of the slot's ID launches on that context (0, 0: none): whose status words are the slot's
     hipEvent_t joined;               // what the caller's stream held when the stream of queries began
     bool *used;
     bool ordered;                    // the lanes already wait for the caller's stream
@@ -1886,7 +2182,7 @@ int pqps_qstream_destroy(pqps_qstream *q) {
     for (uint32_t i = 0; i < q->depth; i++)
         if (q->done && q->done[i]) (void)hipEventDestroy(q->done[i]);
     if (q->joined) (void)hipEventDestroy(q->joined);
-    delete[] q->done; delete[] q->ready; delete[] q->ran_on; delete[] q->child; delete[] q->used;
+    delete[] q->done; delete[] q->ready; delete[] q->ran_on; delete[] q->child; delete[] q->used; delete[] q->ep_lo; delete[] q->ep_hi;
     delete q;
     return PQPS_OK;
 }
@@ -1897,11 +2193,11 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
     pqps_qstream *q = new (std::nothrow) pqps_qstream();
     if (!q) return fail(PQPS_ENOMEM, "out of host memory");
     q->ctx = ctx; q->depth = depth;
-    static const int lanes_env = [] { const char *e = getenv("PQPS_QSTREAM_LANES"); return e ? atoi(e) : 0; }();
+    static const int lanes_env = [] { const char *e = tuning_env("PQPS_QSTREAM_LANES"); return e ? atoi(e) : 0; }();
     q->lanes = lanes_env >= 1 && lanes_env <= 8 ? (uint32_t)lanes_env : 2u;
     if (q->lanes > depth) q->lanes = depth;
     q->child = new pqps_ctx *[q->lanes](); q->done = new hipEvent_t[depth](); q->ready = new hipEvent_t[depth]();
-    q->ran_on = new pqps_ctx *[depth](); q->used = new bool[depth]();
+    q->ran_on = new pqps_ctx *[depth](); q->used = new bool[depth](); q->ep_lo = new uint32_t[depth](); q->ep_hi = new uint32_t[depth]();
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&q->joined, hipEventDisableTiming);
     for (uint32_t i = 0; i < depth && e == hipSuccess; i++) e = hipEventCreateWithFlags(&q->done[i], hipEventDisableTiming);
@@ -1917,7 +2213,7 @@ int pqps_qstream_create(pqps_ctx *ctx, uint32_t depth, pqps_qstream **out) {
 namespace {
 
 bool one_lane_table(uint64_t n_rows) {
-    static const char *env = getenv("PQPS_QSTREAM_ONE_LANE_ROWS");      // tuning runs
+    static const char *env = tuning_env("PQPS_QSTREAM_ONE_LANE_ROWS");      // tuning runs
     const uint64_t from = env ? strtoull(env, nullptr, 10) : kInterleaveFromGroups * (uint64_t)kGroupSteps * kStepRows;
     return n_rows >= from;
 }
@@ -1965,10 +2261,13 @@ int qstream_issue(pqps_qstream *q, uint32_t slot, int mode, const pqps_column *c
         s = c->stream;
     }
     hipEvent_t ev = q->done[slot];
+    const uint32_t before = c->epoch;
     rc = run_filter(c, k1, a, n_rows, mode, false, id_base, out_ids, out_capacity, out_count, s, &ev);
     if (rc) return rc;
     q->ready[slot] = ev;
     q->ran_on[slot] = c;
+    // the launch's epoch (run_filter commits it once the launch is in the queue; COUNT and an empty table launch no ID kernel)
+    q->ep_lo[slot] = q->ep_hi[slot] = (mode == MODE_IDS && n_rows != 0 && (c->epoch != before || before == 0)) ? c->epoch : 0u;
     q->used[slot] = true;
     q->seq++;
     return PQPS_OK;
@@ -2011,6 +2310,8 @@ int pqps_qstream_lane(pqps_qstream *q, uint32_t slot, uint64_t n_rows, void *sca
     int rc = qstream_begin(q, slot, n_rows, pick_stream(q->ctx, scan_stream), &c);
     if (rc) return rc;
     q->ran_on[slot] = c;
+    q->ep_lo[slot] = c->epoch;                                   // (pqps_qstream_mark turns this into the range of the calls in between)
+    q->ep_hi[slot] = 0;
     q->seq++;
     *lane_ctx = c;
     *lane_stream = (void *)c->stream;
@@ -2026,6 +2327,12 @@ int pqps_qstream_mark(pqps_qstream *q, uint32_t slot) {
     (void)hipSetDevice(q->ctx->device);
     HIP_TRY(hipEventRecord(q->done[slot], q->ran_on[slot]->stream));
     q->ready[slot] = q->done[slot];
+    {   // the ID launches the caller issued on the lane since pqps_qstream_lane: epochs (first, now]
+        const uint32_t first = q->ep_lo[slot], now = q->ran_on[slot]->epoch;
+        if (now == first) { q->ep_lo[slot] = q->ep_hi[slot] = 0; }
+        else if (now > first) { q->ep_lo[slot] = first + 1u; q->ep_hi[slot] = now; }
+        else { q->ep_lo[slot] = 1u; q->ep_hi[slot] = 0xFFFFFFFFu; }       // the epochs started over in between: any word
+    }
     q->used[slot] = true;
     return PQPS_OK;
 }
@@ -2037,7 +2344,32 @@ int pqps_qstream_wait(pqps_qstream *q, uint32_t slot) {
     if (!q->used[slot]) return PQPS_OK;
     (void)hipSetDevice(q->ctx->device);
     HIP_TRY(hipEventSynchronize(q->ready[slot]));
-    return take_status(q->ran_on[slot], "query");
+    if (q->ran_on[slot] == q->ctx) return take_status(q->ctx, "query");       // (timing mode: one query at a time on the parent context)
+    return take_status_of(q->ran_on[slot], q->ep_lo[slot], q->ep_hi[slot], "query");
+}
+
+// Test hook: marks the slot's (last) ID launch as one that gave up, the way the kernel would -- what pqps_qstream_wait must
+// then report for THIS slot and for no other that ran on the same lane.
+int pqps_qstream_test_fail_slot(pqps_qstream *q, uint32_t slot) {
+    if (!q || slot >= q->depth || !q->used[slot] || q->ep_hi[slot] == 0 || q->ep_hi[slot] == 0xFFFFFFFFu) return fail(PQPS_EINVAL, "slot %u has no ID launch", slot);
+    const uint32_t e = q->ep_hi[slot];
+    ((volatile uint32_t *)q->ran_on[slot]->status_host)[e & (kStatusWords - 1u)] = e;
+    return PQPS_OK;
+}
+
+// Reserves the lanes' scratch (hand-off words, slots, the list area of ID scans) for tables of up to n_rows rows now instead
+// of inside the first queries: an engine does this when it builds its table.
+int pqps_qstream_reserve(pqps_qstream *q, uint64_t n_rows) {
+    if (!q) return fail(PQPS_EINVAL, "qstream is NULL");
+    HIP_TRY(hipSetDevice(q->ctx->device));
+    const uint64_t steps = (n_rows + kStepRows - 1) / kStepRows;
+    for (uint32_t i = 0; i < q->lanes; i++) {
+        const int rc = ensure_scratch(q->child[i], steps);
+        if (rc) return rc;
+        if ((steps + kGroupSteps - 1) / kGroupSteps < kInterleaveFromGroups)
+            (void)ensure_lists(q->child[i], steps);              // (larger tables scan without lists; refused: bit masks, same results)
+    }
+    return PQPS_OK;
 }
 
 uint64_t pqps_qstream_wait_ns(pqps_qstream *q, int reset) {
@@ -2092,5 +2424,22 @@ int pqps_copy_peer(pqps_ctx *dst_ctx, void *dst, pqps_ctx *src_ctx, const void *
 }
 
 int pqps_ctx_device(pqps_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int pqps_ids_checksum(pqps_ctx *ctx, const uint32_t *ids, uint64_t count, uint64_t out[2], void *stream) {
+    if (!ctx || !out || (count && !ids)) return fail(PQPS_EINVAL, "NULL argument");
+    hipStream_t s = pick_stream(ctx, stream);
+    if (!ctx->check_dev) HIP_TRY(hipMalloc((void **)&ctx->check_dev, 2 * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync(ctx->check_dev, 0, 2 * sizeof(uint64_t), s));
+    if (count) {
+        uint64_t blocks = (count + 1023) / 1024;
+        const uint64_t cap = (uint64_t)ctx->compute_units * 8;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(ids_checksum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, ids, count, ctx->check_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(out, ctx->check_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return PQPS_OK;
+}
 
 }  // extern "C"

@@ -16,6 +16,7 @@
 #include "buildEngine-hip.h"
 #include "hipPredicate.h"
 
+#include <errno.h>
 #include <malloc.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -462,6 +463,8 @@ static void shard_lanes_create(struct hipTable *sh, int n_lanes) {
     sh->n_lanes = n_lanes;
     for (int k = 0; k < n_lanes; k++) lane_alloc(sh, &sh->lane[k], true);
     if (pqps_qstream_create(sh->ctx, (uint32_t)n_lanes, &sh->qs) != PQPS_OK) hip_die("query stream");
+    /* the scan lanes' scratch and list area now, not inside the first ID queries (2.5 bytes per row and lane) */
+    if (pqps_qstream_reserve(sh->qs, sh->capacity_rows) != PQPS_OK) hip_die("query stream scratch");
 }
 
 /* Buffers of one shard for rows [row0, row0 + count): capacity leaves head-room so that INSERT appends in place; the
@@ -562,23 +565,39 @@ static void dictionary_free(struct hipDictionary *d) {
 }
 
 /* Readers (SELECT / COUNT, each on a lane of its own) and writers (INSERT / DELETE / index creation, alone).  A
- * reader may end on another thread than it began on (asynchronous tickets), which a pthread rwlock does not allow. */
+ * reader may end on another thread than it began on (asynchronous tickets), which a pthread rwlock does not allow.
+ *
+ * Rules that keep a caller from waiting for itself (include/executeEngine-hip.h states them for the API's users):
+ *   - waiting writers go first, EXCEPT that a thread which already holds a lane (a ticket of its own that is not released
+ *     yet) is let in beside them: the writer waits for that thread's tickets, so holding the thread back would hold the
+ *     writer back for ever;
+ *   - a writer call from a thread that holds a lane is refused (it would wait for its own ticket);
+ *   - a thread that asks for a lane while it holds every lane itself is refused at once; any other wait for a lane ends
+ *     after PQPS_LANE_WAIT_MS (default 10 000) with a refusal instead of hanging a process that has touched the GPU. */
 struct hipLocks {
     pthread_mutex_t m;
     pthread_cond_t cv;
     int readers, writer, writers_waiting;
     unsigned busy_lanes;                 /* bit k: lane k is taken */
     int n_lanes;
+    pthread_t lane_owner[HIP_MAX_LANES]; /* the thread that took lane k (valid while its busy bit is set) */
+    long lane_wait_ms;
     pthread_mutex_t issue;               /* issuing calls on the shards' query streams */
 };
 
 static struct hipLocks *locks_create(int n_lanes) {
     struct hipLocks *l = calloc(1, sizeof *l);
-    if (!l || pthread_mutex_init(&l->m, NULL) != 0 || pthread_cond_init(&l->cv, NULL) != 0 || pthread_mutex_init(&l->issue, NULL) != 0) {
+    pthread_condattr_t ca;
+    if (!l || pthread_mutex_init(&l->m, NULL) != 0 || pthread_condattr_init(&ca) != 0 ||
+        pthread_condattr_setclock(&ca, CLOCK_MONOTONIC) != 0 || pthread_cond_init(&l->cv, &ca) != 0 ||
+        pthread_mutex_init(&l->issue, NULL) != 0) {
         perror("Failed to create engine locks");
         exit(EXIT_FAILURE);
     }
+    pthread_condattr_destroy(&ca);
     l->n_lanes = n_lanes;
+    const char *env = getenv("PQPS_LANE_WAIT_MS");
+    l->lane_wait_ms = env && atol(env) >= 0 ? atol(env) : 10000;
     return l;
 }
 
@@ -590,11 +609,25 @@ static void locks_destroy(struct hipLocks *l) {
     free(l);
 }
 
+/* Test hooks (tests/c/locks_test.c exercises the gate on a table that has nothing but locks -- no device). */
+void hipTableLocksCreate(struct hipTable *t, int n_lanes) { t->locks = locks_create(n_lanes > HIP_MAX_LANES ? HIP_MAX_LANES : n_lanes); }
+void hipTableLocksDestroy(struct hipTable *t) { locks_destroy(t->locks); t->locks = NULL; }
+
+/* (caller holds l->m) lanes the calling thread has taken and not given back */
+static int lanes_of_self(const struct hipLocks *l) {
+    int k, n = 0;
+    const pthread_t self = pthread_self();
+    for (k = 0; k < l->n_lanes; k++)
+        if ((l->busy_lanes & (1u << k)) && pthread_equal(l->lane_owner[k], self)) n++;
+    return n;
+}
+
 void hipTableLockShared(struct hipTable *t) {
     if (!t || !t->locks) return;
     struct hipLocks *l = t->locks;
     pthread_mutex_lock(&l->m);
-    while (l->writer || l->writers_waiting) pthread_cond_wait(&l->cv, &l->m);      /* writers first: a stream of readers cannot starve them */
+    /* writers first (a stream of readers cannot starve them) -- but not in front of a thread they are waiting for */
+    while (l->writer || (l->writers_waiting && lanes_of_self(l) == 0)) pthread_cond_wait(&l->cv, &l->m);
     l->readers++;
     pthread_mutex_unlock(&l->m);
 }
@@ -607,15 +640,21 @@ void hipTableUnlockShared(struct hipTable *t) {
     pthread_mutex_unlock(&l->m);
 }
 
-void hipTableLockExclusive(struct hipTable *t) {
-    if (!t || !t->locks) return;
+int hipTableLockExclusive(struct hipTable *t) {
+    if (!t || !t->locks) return 0;
     struct hipLocks *l = t->locks;
     pthread_mutex_lock(&l->m);
+    if (lanes_of_self(l) > 0) {                                   /* would wait for a ticket only this thread can release */
+        pthread_mutex_unlock(&l->m);
+        fprintf(stderr, "HIP engine: INSERT / DELETE / index calls are refused while the calling thread holds a query ticket (release it first)\n");
+        return -1;
+    }
     l->writers_waiting++;
     while (l->writer || l->readers) pthread_cond_wait(&l->cv, &l->m);
     l->writers_waiting--;
     l->writer = 1;
     pthread_mutex_unlock(&l->m);
+    return 0;
 }
 
 void hipTableUnlockExclusive(struct hipTable *t) {
@@ -630,14 +669,31 @@ void hipTableUnlockExclusive(struct hipTable *t) {
 int hipTableAcquireLane(struct hipTable *t) {
     if (!t || !t->locks || t->locks->n_lanes == 0) return -1;
     struct hipLocks *l = t->locks;
+    struct timespec deadline;
+    clock_gettime(CLOCK_MONOTONIC, &deadline);
+    deadline.tv_sec += l->lane_wait_ms / 1000;
+    deadline.tv_nsec += (l->lane_wait_ms % 1000) * 1000000L;
+    if (deadline.tv_nsec >= 1000000000L) { deadline.tv_sec++; deadline.tv_nsec -= 1000000000L; }
     pthread_mutex_lock(&l->m);
     int k;
     for (;;) {
         for (k = 0; k < l->n_lanes; k++) if (!(l->busy_lanes & (1u << k))) break;
         if (k < l->n_lanes) break;
-        pthread_cond_wait(&l->cv, &l->m);
+        if (lanes_of_self(l) == l->n_lanes) {                     /* every lane is this thread's own: nobody else can free one */
+            pthread_mutex_unlock(&l->m);
+            fprintf(stderr, "HIP engine: the calling thread already holds all %d query lanes (PQPS_ENGINE_LANES): release a ticket first\n", l->n_lanes);
+            return HIP_LANE_REFUSED;
+        }
+        if (pthread_cond_timedwait(&l->cv, &l->m, &deadline) == ETIMEDOUT) {
+            for (k = 0; k < l->n_lanes; k++) if (!(l->busy_lanes & (1u << k))) break;
+            if (k < l->n_lanes) break;
+            pthread_mutex_unlock(&l->m);
+            fprintf(stderr, "HIP engine: no query lane came free within %ld ms (%d lanes, all held by unreleased tickets)\n", l->lane_wait_ms, l->n_lanes);
+            return HIP_LANE_REFUSED;
+        }
     }
     l->busy_lanes |= 1u << k;
+    l->lane_owner[k] = pthread_self();
     pthread_mutex_unlock(&l->m);
     return k;
 }
@@ -650,6 +706,8 @@ void hipTableReleaseLane(struct hipTable *t, int lane) {
     pthread_cond_broadcast(&l->cv);
     pthread_mutex_unlock(&l->m);
 }
+
+int hipTableLaneCount(const struct hipTable *t) { return t && t->locks ? t->locks->n_lanes : 0; }
 
 void hipTableLockIssue(struct hipTable *t) { if (t && t->locks) pthread_mutex_lock(&t->locks->issue); }
 void hipTableUnlockIssue(struct hipTable *t) { if (t && t->locks) pthread_mutex_unlock(&t->locks->issue); }
@@ -690,6 +748,7 @@ static void table_release(struct hipTable *t, int n_indexes) {
 
 void hipTableFree(struct hipTable *t, int n_indexes) {
     if (!t) return;
+    if (t->xch) { pqps_exchange_destroy(t->xch); t->xch = NULL; }   /* before the contexts its lanes were made on */
     table_release(t, n_indexes);
     locks_destroy(t->locks);
     free(t);
@@ -738,11 +797,14 @@ bool makeIndexHIP(struct engineS *engine, const char *indexName, int attributeTy
 }
 
 /* What makes a table an ENGINE's table: query lanes on every shard and the locks. */
-static void table_make_engine(struct hipTable *t) {
-    const int n_lanes = engine_lanes();
+static void table_make_engine_lanes(struct hipTable *t, int min_lanes) {
+    int n_lanes = engine_lanes();
+    if (n_lanes < min_lanes) n_lanes = min_lanes > HIP_MAX_LANES ? HIP_MAX_LANES : min_lanes;
     for (int s = 0; s < hipTableShards(t); s++) shard_lanes_create(hipTableShard(t, s), n_lanes);
     if (!t->locks) t->locks = locks_create(n_lanes);
 }
+
+static void table_make_engine(struct hipTable *t) { table_make_engine_lanes(t, 1); }
 
 bool buildDeviceTableHIP(struct engineS *engine) {
     struct hipContextFuture *f = hipBeginContextHIP();
@@ -1052,7 +1114,20 @@ const char *const *hipSyntheticDictionary(int column, int *count) {
     return d;
 }
 
+static bool synthetic_table(struct engineS *engine, unsigned long long num_rows, unsigned long long seed, unsigned long long first_row,
+                            bool one_shard, int min_lanes);
+
 bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed) {
+    return synthetic_table(engine, num_rows, seed, 0, false, 1);
+}
+
+bool buildSyntheticShardDeviceTableHIP(struct engineS *engine, unsigned long long num_rows, unsigned long long seed,
+                                       unsigned long long first_row, int min_lanes) {
+    return synthetic_table(engine, num_rows, seed, first_row, true, min_lanes);
+}
+
+static bool synthetic_table(struct engineS *engine, unsigned long long num_rows, unsigned long long seed, unsigned long long first_row,
+                            bool one_shard, int min_lanes) {
     struct hipColumnData columns[HIPCOL_COUNT];
     memset(columns, 0, sizeof columns);
     static const char dummy = 0;                                     /* "values will be generated": not NULL */
@@ -1064,6 +1139,10 @@ bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num
     pqps_ctx **ctxs = NULL;
     int n_shards = 0;
     struct hipTable *t = columns_table(num_rows, columns, &ctxs, &n_shards);
+    if (one_shard) {
+        if (n_shards != 1) { fprintf(stderr, "HIP engine: a rank's part of a table lives on ONE device (PQPS_DEVICES names several)\n"); exit(EXIT_FAILURE); }
+        t->row0 = first_row;                                         /* the shard's rows carry the table-wide row numbers */
+    }
     uint32_t *cdf = malloc(PQPS_SYNTH_USERS * sizeof *cdf);
     uint8_t *shell = malloc(PQPS_SYNTH_USERS);
     if (!cdf || !shell) { perror("Failed to allocate memory for the synthetic table"); exit(EXIT_FAILURE); }
@@ -1091,7 +1170,7 @@ bool buildSyntheticDeviceTableHIP(struct engineS *engine, unsigned long long num
         pqps_free(sh->ctx, shell_dev);
     }
     free(cdf); free(shell); free(ctxs);
-    table_make_engine(t);
+    table_make_engine_lanes(t, min_lanes);
     engine->record_block = t;
     return true;
 }

@@ -187,6 +187,7 @@ struct query {
     uint64_t count[HIP_MAX_SHARDS];
     const uint32_t *ids_dev;
     pqps_ctx *ids_ctx;                   /* a context of the device ids_dev lives on (downloads) */
+    bool exchanged;                      /* issued through the ranks' exchange: the answer is the exchange slot's */
 };
 
 static struct hipLane *query_lane(const struct query *q, int s) {
@@ -277,6 +278,23 @@ static int issue_on_shard(struct query *q, int s) {
     const struct hipPlan *plan = &q->plan;
     const struct hipPass *last = &plan->pass[plan->n_passes - 1];
     const bool single = plan->n_passes == 1 && q->n_probes == 0;
+    if (q->t->xch) {
+        /* one process per GPU: the shard's scan + the exchange with the other ranks, one call (mpi:717-768).  Every rank has
+         * to issue the same queries in the same order; index probes and WHERE lists of several passes stay local matters */
+        if (!single || q->lane < 0) {
+            fprintf(stderr, "HIP engine: across ranks only scan-mode queries of one pass are exchanged (no index probes, at most %d comparisons)\n", PQPS_MAX_LEAVES);
+            return -1;
+        }
+        sp->pred = &last->pred;
+        sp->n_cols = last->pred.n_columns;
+        pass_columns(sh, last, NULL, sp->cols);
+        if (q->count_only)
+            TRY(pqps_exchange_count(q->t->xch, sp->cols, sp->n_cols, sh->n_rows, sp->pred, (uint32_t)q->lane, NULL), "count exchange");
+        else
+            TRY(pqps_exchange_select(q->t->xch, sp->cols, sp->n_cols, sh->n_rows, (uint32_t)sh->row0, sp->pred, (uint32_t)q->lane, NULL), "scan exchange");
+        q->exchanged = true;
+        return 0;
+    }
     if (q->lane >= 0 && single) {
         sp->pred = &last->pred;
         sp->n_cols = last->pred.n_columns;
@@ -322,6 +340,7 @@ static int query_issue(struct query *q, struct whereClauseS *where) {
 
 static int wait_shard(struct query *q, int s) {
     struct hipTable *sh = hipTableShard(q->t, s);
+    if (q->exchanged || (q->t->xch && q->lane >= 0)) return 0;      /* (the exchange's own slot waits cover it) */
     if (q->lane >= 0) TRY(pqps_qstream_wait(sh->qs, (uint32_t)q->lane), "filter execution");
     else TRY(pqps_ctx_sync(sh->ctx, NULL), "filter execution");
     return 0;
@@ -425,6 +444,17 @@ static int gather_shards(struct query *q) {
 /* Waits for the query; a result buffer that turned out too small (index-mode duplicates can exceed the table's rows)
  * is grown and the query issued again. */
 static int query_await(struct query *q) {
+    if (q->exchanged) {
+        /* every rank holds the whole answer: the shards' lists gathered in rank order (= ascending row numbers) */
+        const uint32_t *merged = NULL;
+        uint64_t local = 0, totals[2] = { 0, 0 };
+        TRY(pqps_exchange_result(q->t->xch, (uint32_t)q->lane, q->count_only ? NULL : &merged, &local, totals), "exchange result");
+        q->total = totals[0];
+        q->count[0] = local;
+        q->ids_dev = merged;
+        q->ids_ctx = lane_copy_ctx(q, 0);
+        return 0;
+    }
     for (;;) {
         bool again = false;
         int rc = 0;
@@ -470,7 +500,13 @@ static struct hipQueryTicket *ticket_begin(struct engineS *engine, struct whereC
     if (!tk) { fprintf(stderr, "HIP engine: out of memory\n"); return NULL; }
     tk->t0 = now_seconds();
     hipTableLockShared(t);                                            /* until releaseQueryHIP: no writer meanwhile */
-    query_init(&tk->q, engine, t, hipTableAcquireLane(t), count_only);
+    const int lane = hipTableAcquireLane(t);
+    if (lane == HIP_LANE_REFUSED) {                                   /* reason on stderr: the caller holds every lane itself, or none came free in time */
+        hipTableUnlockShared(t);
+        free(tk);
+        return NULL;
+    }
+    query_init(&tk->q, engine, t, lane, count_only);
     if (query_issue(&tk->q, where) != 0) tk->state = -1;            /* reason on stderr; awaitQueryHIP reports -1 */
     return tk;
 }
@@ -496,6 +532,100 @@ long long awaitQueryHIP(struct hipQueryTicket *tk, struct hipDeviceResult *resul
         for (int s = 0; s < tk->q.n_shards && s < 16; s++) result->shard_count[s] = tk->q.count[s];
     }
     return (long long)tk->q.total;
+}
+
+/* Checksums of the answer's ID list where it lies, on the device (pqps_ids_checksum): what a driver compares the list of
+ * a timed query with -- against another path's list, or against numpy over the oracle's -- without moving it. */
+int hipQueryChecksumHIP(struct hipQueryTicket *tk, unsigned long long out[2]) {
+    if (!tk || !out) return -1;
+    const long long count = awaitQueryHIP(tk, NULL);
+    if (count < 0 || tk->q.count_only) return -1;
+    uint64_t sums[2] = { 0, 0 };
+    if (count > 0 && pqps_ids_checksum(tk->q.ids_ctx, tk->q.ids_dev, (uint64_t)count, sums, NULL) != PQPS_OK) return engine_error("ID checksum");
+    out[0] = sums[0];
+    out[1] = sums[1];
+    return 0;
+}
+
+/* ---- one process per GPU ----------------------------------------------------------------------------------- */
+static struct engineS *engine_shell(unsigned long long num_rows, const char *tableName);
+static void probe_mode_from_env(struct engineS *engine);
+
+struct engineS *initializeEngineSyntheticRankHIP(unsigned long long rows_total, unsigned long long seed, int world, int rank,
+                                                 const char *tableName) {
+    if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "HIP engine: rank %d of %d\n", rank, world); return NULL; }
+    if (rows_total > 0xFFFFFFFFull) { fprintf(stderr, "HIP engine: row numbers are 32 bits wide: %llu rows\n", rows_total); return NULL; }
+    uint64_t start = 0, count = 0;
+    pqps_partition(rows_total, world, rank, &start, &count);       /* mpi:703-715 */
+    struct engineS *engine = engine_shell(count, tableName);
+    if (!engine) return NULL;
+    /* six lanes: the exchange holds the payload of two queries back behind the scans in flight (pqps_exchange_select) */
+    buildSyntheticShardDeviceTableHIP(engine, count, seed, start, 6);
+    struct hipTable *t = engine->record_block;
+    t->world = world;
+    t->rank = rank;
+    t->rows_total = rows_total;
+    probe_mode_from_env(engine);
+    return engine;
+}
+
+int hipEngineRcclIdHIP(const char *rccl_library, void *id128) {
+    if (!id128) return -1;
+    if (pqps_exchange_unique_id(rccl_library, (pqps_rccl_id *)id128) != PQPS_OK) return engine_error("RCCL id");
+    return 0;
+}
+
+int hipEngineJoinPrepareHIP(struct engineS *engine, const char *rccl_library) {
+    if (!engine || !engine->record_block) return -1;
+    struct hipTable *t = engine->record_block;
+    if (t->world < 1 || hipTableShards(t) != 1 || t->xch) { fprintf(stderr, "HIP engine: not a rank's engine, or joined already\n"); return -1; }
+    if (hipTableLockExclusive(t) != 0) return -1;
+    const int rc = pqps_exchange_prepare(t->ctx, rccl_library, (uint32_t)t->world, (uint32_t)t->rank, t->capacity_rows, (uint32_t)t->n_lanes, &t->xch);
+    hipTableUnlockExclusive(t);
+    if (rc != PQPS_OK) { t->xch = NULL; return engine_error("exchange set-up"); }
+    return 0;
+}
+
+int hipEngineJoinConnectHIP(struct engineS *engine, const void *id128) {
+    if (!engine || !engine->record_block || !id128) return -1;
+    struct hipTable *t = engine->record_block;
+    if (!t->xch) return -1;
+    if (pqps_exchange_connect(t->xch, (const pqps_rccl_id *)id128) != PQPS_OK) {
+        engine_error("communicator");
+        pqps_exchange_destroy(t->xch);
+        t->xch = NULL;
+        return -1;
+    }
+    return 0;
+}
+
+int hipEngineJoinRanksHIP(struct engineS *engine, const char *rccl_library, const void *id128) {
+    if (hipEngineJoinPrepareHIP(engine, rccl_library) != 0) return -1;
+    return hipEngineJoinConnectHIP(engine, id128);
+}
+
+int hipEngineLeaveRanksHIP(struct engineS *engine) {
+    if (!engine || !engine->record_block) return -1;
+    struct hipTable *t = engine->record_block;
+    if (hipTableLockExclusive(t) != 0) return -1;                   /* every ticket is released */
+    if (t->xch) { pqps_exchange_destroy(t->xch); t->xch = NULL; }
+    hipTableUnlockExclusive(t);
+    return 0;
+}
+
+int hipEngineWireBytesHIP(struct engineS *engine, unsigned long long out[2], int reset) {
+    if (!engine || !engine->record_block || !out) return -1;
+    struct hipTable *t = engine->record_block;
+    uint64_t b[2] = { 0, 0 };
+    if (t->xch) pqps_exchange_wire_bytes(t->xch, b, reset);
+    out[0] = b[0];
+    out[1] = b[1];
+    return 0;
+}
+
+int hipEngineLanes(struct engineS *engine) {
+    if (!engine || !engine->record_block) return -1;
+    return hipTableLaneCount(engine->record_block);
 }
 
 /* The lane goes back (its device buffers are no longer this query's); the table stays locked shared. */
@@ -726,7 +856,9 @@ static int project_column(struct query *q, int c, void *const *gathered, bool sc
 static int select_columnar(struct engineS *engine, struct hipTable *t, const char **selectItems, int numSelectItems,
                            struct whereClauseS *whereClause, struct hipColumnarResult *res) {
     struct query q;
-    query_init(&q, engine, t, hipTableAcquireLane(t), false);
+    const int lane = hipTableAcquireLane(t);
+    if (lane == HIP_LANE_REFUSED) return -1;                        /* reason on stderr */
+    query_init(&q, engine, t, lane, false);
     int rc = query_issue(&q, whereClause);
     if (rc == 0) rc = query_await(&q);
     else for (int s = 0; s < q.n_shards; s++) (void)wait_shard(&q, s);
@@ -1089,7 +1221,7 @@ void destroyEngineHIP(struct engineS *engine) {
 bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const char *attributeName,
                           int attributeType) {
     (void)tableName;
-    hipTableLockExclusive(engine->record_block);
+    if (hipTableLockExclusive(engine->record_block) != 0) return false;
     const bool ok = makeIndexHIP(engine, attributeName, attributeType);
     hipTableUnlockExclusive(engine->record_block);
     return ok;
@@ -1098,7 +1230,7 @@ bool addAttributeIndexHIP(struct engineS *engine, const char *tableName, const c
 int hipEngineProbeBoolIndexes(struct engineS *engine, int enable) {
     if (!engine || !engine->record_block) return -1;
     struct hipTable *t = engine->record_block;
-    hipTableLockExclusive(t);                                       /* no query in flight while the mode changes */
+    if (hipTableLockExclusive(t) != 0) return -1;                   /* no query in flight while the mode changes */
     const int before = t->probe_bool;
     t->probe_bool = enable != 0;
     hipTableUnlockExclusive(t);
@@ -1109,7 +1241,7 @@ int hipEngineKernelTiming(struct engineS *engine, int enable) {
     if (!engine || !engine->record_block) return -1;
     struct hipTable *t = engine->record_block;
     int rc = 0;
-    hipTableLockExclusive(t);                                       /* no query in flight while the recorders are switched */
+    if (hipTableLockExclusive(t) != 0) return -1;                   /* no query in flight while the recorders are switched */
     for (int s = 0; s < hipTableShards(t) && rc == 0; s++)
         if (hipTableShard(t, s)->qs && pqps_qstream_set_timing(hipTableShard(t, s)->qs, enable) != PQPS_OK) rc = engine_error("kernel timing");
     hipTableUnlockExclusive(t);
@@ -1121,7 +1253,7 @@ int hipEngineKernelTime(struct engineS *engine, double *scan_ms, double *query_m
     struct hipTable *t = engine->record_block;
     *scan_ms = 0.0; *query_ms = 0.0; *launches = 0;
     int rc = 0;
-    hipTableLockExclusive(t);
+    if (hipTableLockExclusive(t) != 0) return -1;
     for (int s = 0; s < hipTableShards(t) && rc == 0; s++) {
         double e = 0.0, q = 0.0;
         int k = 0;
@@ -1239,7 +1371,7 @@ bool executeQueryInsertHIP(struct engineS *engine, const char *tableName, const 
         return false;                                              /* S:544-551 */
     struct hipTable *t = engine->record_block;
     const double t0 = now_seconds();
-    hipTableLockExclusive(t);
+    if (hipTableLockExclusive(t) != 0) return false;
     const size_t n = (size_t)engine->num_records;
     if (t->device_only) {
         /* no host rows, no CSV: the row goes to the device table alone */
@@ -1341,7 +1473,7 @@ struct resultSetS *executeQueryDeleteHIP(struct engineS *engine, const char *tab
     if (!rs) { perror("Failed to allocate memory for result set"); exit(EXIT_FAILURE); }
     const double t0 = now_seconds();
     struct hipTable *t = engine->record_block;
-    hipTableLockExclusive(t);
+    if (hipTableLockExclusive(t) != 0) { memset(rs, 0, sizeof *rs); rs->success = false; return rs; }
     const size_t n = (size_t)engine->num_records;
     const int n_shards = hipTableShards(t);
     uint8_t *flags_dev[HIP_MAX_SHARDS];

@@ -45,6 +45,55 @@ def displacements(sizes, capacities=None):
 
 SLOT_HEADER_WORDS = 4     # include/pqps_hip.h: [u64 count][u64 reserved] in front of the IDs
 
+# ---- the compact wire form (csrc/pqps_hip.hip: wire_pack_kernel / wire_expand_kernel, restated with numpy) ----------
+# A shard's ascending list travels as the low 16 bits of every row number relative to the shard's first row + one u32 per
+# 65 536-row group saying where the group's entries begin: [u32 goff[groups + 1], padded to 16 bytes][u16 low[n]].
+WIRE_GROUP_ROWS = 1 << 16
+WIRE_HEADER_WORDS = 4     # per rank in the sizes all-gather: reported count, rows, first row, form (1 = compact)
+
+
+def wire_groups(n_rows):
+    return (n_rows + WIRE_GROUP_ROWS - 1) // WIRE_GROUP_ROWS
+
+
+def wire_goff_bytes(n_rows):
+    return ((wire_groups(n_rows) + 1) * 4 + 15) & ~15
+
+
+def wire_bytes(n_rows, n_ids):
+    return wire_goff_bytes(n_rows) + ((n_ids * 2 + 3) & ~3)
+
+
+def wire_pays(n_rows, n_ids):
+    return wire_bytes(n_rows, n_ids) < 4 * n_ids
+
+
+def wire_pack_numpy(ids_u32, n_rows, id_base):
+    """uint8 numpy payload of an ascending uint32 list (the CPU twin of wire_pack_kernel)."""
+    import numpy as np
+    rel = (ids_u32.astype(np.uint64) - np.uint64(id_base)).astype(np.uint64)
+    groups = wire_groups(n_rows)
+    goff = np.searchsorted(rel, np.arange(groups + 1, dtype=np.uint64) * np.uint64(WIRE_GROUP_ROWS), side="left").astype(np.uint32)
+    out = np.zeros(wire_bytes(n_rows, len(ids_u32)), dtype=np.uint8)
+    out[:4 * (groups + 1)] = goff.view(np.uint8)
+    low = (rel & np.uint64(0xFFFF)).astype(np.uint16)
+    g0 = wire_goff_bytes(n_rows)
+    out[g0:g0 + 2 * len(low)] = low.view(np.uint8)
+    return out
+
+
+def wire_expand_numpy(wire_u8, n_rows, id_base, n_ids):
+    """The uint32 list a payload stands for (the CPU twin of wire_expand_kernel)."""
+    import numpy as np
+    groups = wire_groups(n_rows)
+    goff = wire_u8[:4 * (groups + 1)].view(np.uint32).astype(np.int64)
+    g0 = wire_goff_bytes(n_rows)
+    low = wire_u8[g0:g0 + 2 * n_ids].view(np.uint16).astype(np.uint64)
+    per_group = np.diff(goff)
+    assert goff[0] == 0 and goff[-1] == n_ids and (per_group >= 0).all(), "malformed compact payload"
+    high = np.repeat(np.arange(groups, dtype=np.uint64) * np.uint64(WIRE_GROUP_ROWS), per_group)
+    return (np.uint64(id_base) + high + low).astype(np.uint32)
+
 
 class IdMerger:
     """Buffers + the exchange for one (world, local capacity), over torch.distributed.
@@ -55,8 +104,14 @@ class IdMerger:
     then finish(k-1): the host waits for the sizes of k-1 while the device already has k to run."""
 
     def __init__(self, torch, dist, world, rank, slot_capacity, device, ctx=None, pq=None, host_staged=False,
-                 always_collective=False):
+                 always_collective=False, shard=None, compact=True):
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        # shard = (rows, first row) of this rank's row range: with it, answers that gain from it travel in the compact
+        # wire form (2 bytes per match + 4 per 65 536-row group, see wire_pack_numpy); without it, u32 IDs
+        self.shard = shard
+        self.compact = bool(compact) and shard is not None
+        self.wire_bytes_in = 0             # payload bytes received from the peers as they travelled ...
+        self.u32_bytes_in = 0              # ... and what the same lists are as u32 IDs
         # host_staged: the collectives run on CPU copies (gloo rehearsal of the GPU control flow on a
         # box where RCCL cannot be used, e.g. several ranks sharing one device); never the fast path
         self.host_staged = host_staged
@@ -70,7 +125,9 @@ class IdMerger:
         self.ctx, self.pq = ctx, pq
         t = torch
         self.slot_local = t.zeros(self.stride, dtype=t.int32, device=device)     # u32 payload, int32 container
-        self.sizes = t.zeros(world, dtype=t.int64, device=device)
+        self.sizes = t.zeros(world * WIRE_HEADER_WORDS, dtype=t.int64, device=device)       # per rank: count, rows, first row, form
+        self.header = t.zeros(WIRE_HEADER_WORDS, dtype=t.int64, device=device)
+        self.wire_out = None               # this rank's payload in compact form (uint8), made in begin()
         self.merged = t.zeros(min(self.cap, 1 << 20), dtype=t.int32, device=device)   # grown to what a query needs
         self.totals = [0, 0]                                                      # merged, reported
         self._pending = False
@@ -112,10 +169,32 @@ class IdMerger:
     def _collective(self):
         return self.world > 1 or self.always_collective
 
+    def _pack(self, stream_ptr=None):
+        """This rank's four header words and, if it pays, its payload in compact form."""
+        t = self.torch
+        rows, base = self.shard if self.shard is not None else (0, 0)
+        if self.device.type == "cuda" and self.compact:
+            # the shim's own kernel (the same one pqps_exchange_select runs)
+            need = wire_bytes(rows, min(self.cap, rows))
+            if self.wire_out is None or self.wire_out.numel() < need:
+                self.wire_out = t.zeros(need + 64, dtype=t.uint8, device=self.device)
+            self.pq.check(self.pq.lib().pqps_wire_pack(self.ctx.h, self.slot_local.data_ptr(), self.cap, rows, base, 1,
+                                                       self.header.data_ptr(), self.wire_out.data_ptr(), stream_ptr), "pqps_wire_pack")
+            return
+        count = self.local_count()
+        held = min(count, self.cap)
+        form = 1 if (self.compact and wire_pays(rows, held)) else 0
+        self.header.copy_(t.tensor([count, rows, base, form], dtype=t.int64))
+        if form:
+            import numpy as np
+            ids = self.slot_local[SLOT_HEADER_WORDS:SLOT_HEADER_WORDS + held].cpu().numpy().view(np.uint32)
+            self.wire_out = t.from_numpy(wire_pack_numpy(ids, rows, base)).to(self.device)
+
     def begin(self, stream_ptr=None):
-        """mpi:753 -- the sizes, enqueued on the current torch stream."""
+        """mpi:753 -- the sizes (with the shard's rows, first row and the form the sender chose), enqueued on the current torch stream."""
         dist, t = self.dist, self.torch
-        mine = self.slot_local[0:2].view(t.int64)
+        self._pack(stream_ptr)
+        mine = self.header
         if not self._collective():
             self.sizes.copy_(mine)
         elif self.host_staged or self.device.type != "cuda":
@@ -127,7 +206,7 @@ class IdMerger:
             dist.all_gather_into_tensor(self.sizes, mine)
         if self.device.type == "cuda":
             if self._sizes_pinned is None:
-                self._sizes_pinned = t.empty(self.world, dtype=t.int64).pin_memory()
+                self._sizes_pinned = t.empty(self.world * WIRE_HEADER_WORDS, dtype=t.int64).pin_memory()
                 self._sizes_ready = t.cuda.Event()
             self._sizes_pinned.copy_(self.sizes, non_blocking=True)
             self._sizes_ready.record()
@@ -139,14 +218,17 @@ class IdMerger:
         self._issued = IdMerger._serial
 
     def finish(self):
-        """mpi:758-765 -- displacements on the host, then exactly count[r] IDs from every peer."""
+        """mpi:758-765 -- displacements on the host, then every peer's list: exactly count[r] IDs, or its compact form
+        (rebuilt to IDs at the displacement)."""
         if not self._pending:
             return
         self._pending = False
         dist, t = self.dist, self.torch
         if self.device.type == "cuda":
             self._sizes_ready.synchronize()
-        sizes = [int(v) for v in self._sizes_host.tolist()]
+        hdr = [int(v) for v in self._sizes_host.tolist()]
+        sizes = hdr[0::WIRE_HEADER_WORDS]
+        rows_of, base_of, form_of = hdr[1::WIRE_HEADER_WORDS], hdr[2::WIRE_HEADER_WORDS], hdr[3::WIRE_HEADER_WORDS]
         held, displ, total = displacements(sizes, self.caps)
         if total > self.merged.numel():
             self.merged = t.zeros(total + total // 4 + 4096, dtype=t.int32, device=self.device)
@@ -154,19 +236,38 @@ class IdMerger:
         self.merged[displ[self.rank]:displ[self.rank] + held[self.rank]] = mine
         if self._collective() and self.world > 1:
             staged = self.host_staged and self.device.type == "cuda"
-            src = mine.cpu() if staged else mine
+            me_compact = bool(form_of[self.rank])
+            out = self.wire_out[:wire_bytes(rows_of[self.rank], held[self.rank])] if me_compact else mine
+            src = out.cpu() if staged else out
             into = t.zeros(total, dtype=t.int32) if staged else self.merged
-            ops = []
+            where = t.device("cpu") if staged else self.device
+            ops, wires = [], {}
             for r in range(self.world):
                 if r == self.rank:
                     continue
                 if held[self.rank]:
                     ops.append(dist.P2POp(dist.isend, src, r))
                 if held[r]:
-                    ops.append(dist.P2POp(dist.irecv, into[displ[r]:displ[r] + held[r]], r))
+                    if form_of[r]:
+                        wires[r] = t.zeros(wire_bytes(rows_of[r], held[r]), dtype=t.uint8, device=where)
+                        ops.append(dist.P2POp(dist.irecv, wires[r], r))
+                        self.wire_bytes_in += wires[r].numel()
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, into[displ[r]:displ[r] + held[r]], r))
+                        self.wire_bytes_in += 4 * held[r]
+                    self.u32_bytes_in += 4 * held[r]
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
+            for r, w in wires.items():
+                if self.device.type == "cuda" and not staged:
+                    self.pq.check(self.pq.lib().pqps_wire_expand(self.ctx.h, w.data_ptr(), rows_of[r], base_of[r],
+                                                                 self.merged.data_ptr() + 4 * displ[r], None), "pqps_wire_expand")
+                    self.ctx.sync()                              # (w is a temporary)
+                else:
+                    import numpy as np
+                    ids = wire_expand_numpy(w.cpu().numpy(), rows_of[r], base_of[r], held[r])
+                    into[displ[r]:displ[r] + held[r]] = t.from_numpy(ids.view(np.int32).copy())
             if staged:
                 for r in range(self.world):
                     if r != self.rank and held[r]:

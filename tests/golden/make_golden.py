@@ -333,6 +333,7 @@ def main():
     (HERE / "print_golden.json").write_text(json.dumps(prt, indent=0))
 
     driver_goldens(csv2k)
+    fifty_k_goldens()
 
     unpinned = [c["name"] + "/" + c["indexes"] for c in sel_out if not c["pinned"]]
     print(f"select cases: {len(sel_out)} ({len(unpinned)} not sent to the reference: {unpinned})")
@@ -620,9 +621,64 @@ def driver_goldens(csv2k):
         (HERE / (out_name[:-4] + "_csv.sha256")).write_text(hashlib.sha256(left).hexdigest() + f" {len(left)}\n")
 
 
+FIFTY_K_ROWS = 50_000
+
+
+def fifty_k_goldens():
+    """BASELINE configs[0] at its stated size: the reference's own SELECT test and dispatcher read commands_50k.csv
+    (tests/serial-SELECT-test.c:12, include/connectEngine.h:11).  The reference's file is an LFS stub and its generator is
+    unseeded, so the 50 k-row CSV comes from the repository's own seeded scripts/make_csv.py -- regenerated wherever it is
+    needed, never committed: its SHA-256 is in the golden, and so is, per query of sample-queries.txt / the SELECT test, what
+    the compiled reference answered (count, SHA-256 of the row numbers, SHA-256 of every projected cell) under the default
+    five indexes and without indexes, plus the SHA-256 of QPESeq's normalised stdout for both sample files and of the CSV
+    each run leaves behind."""
+    import hashlib
+    import shutil
+    ref = q.load_ref()
+    if ref is None:
+        sys.exit("oracle/_ref/libqpeseq_ref.so missing")
+    qpeseq = q.ORACLE_DIR / "_ref" / "QPESeq_ref"
+    out = {"rows": FIFTY_K_ROWS, "generator": "scripts/make_csv.py 50000 <out.csv> (seed 0x5EED)", "select": [], "driver": {}}
+    with tempfile.TemporaryDirectory() as td:
+        td = pathlib.Path(td)
+        csv = td / "commands_50k.csv"
+        subprocess.run([sys.executable, str(q.ROOT / "scripts" / "make_csv.py"), str(FIFTY_K_ROWS), str(csv)], check=True)
+        out["csv_sha256"] = hashlib.sha256(csv.read_bytes()).hexdigest()
+        out["csv_bytes"] = csv.stat().st_size
+        names = ["S1", "S2", "S3", "S4", "S7", "S8", "T_all", "T_proj", "T_risk", "T_shell", "T_and", "T_exit"]
+        for cfg in ("default", "none"):
+            eng = q.RefEngine(csv, INDEX_CONFIGS[cfg])
+            for name in names:
+                sel, where = next((s_, w) for n_, s_, w in SELECT_CASES if n_ == name)
+                sql = compose(sel, where)
+                _head, chain = parse_with_ref(ref, sql)
+                res = eng.select(sql)
+                ids = [int(r[0]) for r in eng.select(compose("command_id", where))["rows"]]     # command_id = row number in this table
+                out["select"].append({"name": name, "indexes": cfg, "sql": sql, "where": q.chain_to_jsonable(chain),
+                                      "num_records": res["numRecords"], "columns": res["columns"],
+                                      "rows_sha256": sha_rows(res["rows"]),
+                                      "ids_sha256": hashlib.sha256(b"".join(i.to_bytes(4, "little") for i in ids)).hexdigest(),
+                                      "first_ids": ids[:5]})
+            eng.close()
+        for src in ("sample-queries.txt", "sample-queries-FULL.txt"):
+            run = td / ("run_" + src)
+            run.mkdir()
+            shutil.copy(csv, run / "data.csv")
+            shutil.copy(HERE / src, run / "sample-queries.txt")
+            text = subprocess.run([str(qpeseq), "data.csv"], cwd=run, capture_output=True, check=True).stdout.decode("latin-1")
+            left = (run / "data.csv").read_bytes()
+            out["driver"][src] = {"stdout_sha256": hashlib.sha256(normalize_driver_output(text).encode("latin-1")).hexdigest(),
+                                  "stdout_lines": normalize_driver_output(text).count("\n"),
+                                  "csv_left_sha256": hashlib.sha256(left).hexdigest(), "csv_left_bytes": len(left)}
+    (HERE / "commands_50k_golden.json").write_text(json.dumps(out, indent=0))
+    print(f"50 k-row goldens: {len(out['select'])} SELECT cases, 2 driver runs")
+
+
 if __name__ == "__main__":
     import sys
-    if "--driver-only" in sys.argv:
+    if "--50k-only" in sys.argv:
+        fifty_k_goldens()
+    elif "--driver-only" in sys.argv:
         driver_goldens(HERE / "commands_2k.csv")
     elif "--wide-only" in sys.argv:
         wide_goldens(HERE / "commands_2k.csv")

@@ -13,9 +13,14 @@
 //   * ncclSend / ncclRecv inside ncclGroupStart / ncclGroupEnd form one operation; the k-th receive from peer p matches
 //     p's k-th send to this rank and the counts must agree;
 //   * ncclCommAbort wakes every waiting rank with an error.
+// A STALL can be injected (tests of the exchange's bounded waits): LOOPBACK_STALL="<rank>:<op>" makes that rank's op number
+// <op> (0-based, counted per communicator) never finish ON THE DEVICE -- a kernel spinning on a host flag sits in the
+// rank's stream behind the op's copies, and the peers' streams wait for that rank as they would for a stuck RCCL kernel --
+// until ncclCommAbort raises the flag (or 60 s pass).  Host calls return as usual: what hangs is the stream.
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -40,6 +45,10 @@ struct Desc {
 };
 
 struct World {
+    volatile uint32_t *abort_flag_host = nullptr;   // mapped host word the stall kernel polls
+    uint32_t *abort_flag_dev = nullptr;
+    int stall_rank = -1;
+    uint64_t stall_op = 0;
     int nranks = 0, joined = 0, left = 0;
     std::mutex m;
     std::condition_variable cv;
@@ -85,6 +94,12 @@ int barrier(World *w) {
     if (++w->arrived == w->nranks) { w->arrived = 0; w->generation++; w->cv.notify_all(); return kOk; }
     w->cv.wait(lk, [&] { return w->generation != gen || w->aborted; });
     return w->aborted ? kInternalError : kOk;
+}
+
+// the injected stall: one lane polls the flag (bounded: 60 s of the 100 MHz wall clock)
+__global__ void stall_kernel(const uint32_t *flag) {
+    const uint64_t deadline = wall_clock64() + 6000000000ull;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u && wall_clock64() < deadline) __builtin_amdgcn_s_sleep(64);
 }
 
 __global__ void sum_u64_kernel(const uint64_t *parts, int n, size_t count, uint64_t *out) {
@@ -166,6 +181,10 @@ int run_op(Comm *c, Desc &&mine, hipStream_t s) {
             if (pd.kind != 2 || !taken) { fprintf(stderr, "loopback_rccl: rank %d sends to rank %d, which does not receive\n", me, op.peer); rc = kInvalidUsage; }
         }
     }
+    if (!rc && w->stall_rank == me && c->ops - 1 == w->stall_op && w->abort_flag_dev) {
+        hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, s, w->abort_flag_dev);     // this op never finishes on this rank's stream
+        if (hipGetLastError() != hipSuccess) rc = kUnhandledHip;
+    }
     if (hipEventRecord(w->done[par][me], s) != hipSuccess && !rc) rc = kUnhandledHip;
     if (rc) { std::lock_guard<std::mutex> lk(w->m); w->aborted = true; w->cv.notify_all(); return rc; }
     rc = barrier(w);
@@ -199,7 +218,20 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank) {
         std::lock_guard<std::mutex> lk(g_lock);
         const std::string key(id.internal, strnlen(id.internal, sizeof id.internal));
         auto it = g_worlds.find(key);
-        if (it == g_worlds.end()) { w = new World(); w->nranks = nranks; g_worlds[key] = w; } else w = it->second;
+        if (it == g_worlds.end()) {
+            w = new World(); w->nranks = nranks; g_worlds[key] = w;
+            if (const char *st = getenv("LOOPBACK_STALL")) {
+                int r = -1; unsigned long long op = 0;
+                if (sscanf(st, "%d:%llu", &r, &op) == 2 && r >= 0 && r < nranks) {
+                    void *h = nullptr, *d = nullptr;
+                    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                        memset(h, 0, 64);
+                        w->abort_flag_host = (volatile uint32_t *)h; w->abort_flag_dev = (uint32_t *)d;
+                        w->stall_rank = r; w->stall_op = op;
+                    }
+                }
+            }
+        } else w = it->second;
     }
     if (w->nranks != nranks) return kInvalidArgument;
     for (int par = 0; par < 2; par++) {
@@ -227,7 +259,7 @@ int ncclCommDestroy(void *comm) {
 int ncclCommAbort(void *comm) {
     Comm *c = (Comm *)comm;
     if (!c) return kOk;
-    { std::lock_guard<std::mutex> lk(c->w->m); c->w->aborted = true; c->w->cv.notify_all(); }
+    { std::lock_guard<std::mutex> lk(c->w->m); c->w->aborted = true; if (c->w->abort_flag_host) *c->w->abort_flag_host = 1u; c->w->cv.notify_all(); }
     return ncclCommDestroy(comm);
 }
 

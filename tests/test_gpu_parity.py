@@ -436,9 +436,11 @@ def test_bench_exchange_path_runs_on_one_gpu():
     import json
     import subprocess
     import sys
-    for mode in ("rccl", "torch"):
-        p = subprocess.run([sys.executable, str(q.ROOT / "bench.py"), "--rows", "3000000", "--steps", "9", "--warmup", "2",
-                            "--no-extras", "--no-cpu-baseline", "--force-merge", "--exchange", mode],
+    # (level, exchange) -> who drives the exchange: the engine API in C (hipEngineJoinRanksHIP: round 4), the shim from
+    # Python (pqps_exchange_*), torch.distributed (merge.IdMerger)
+    for level, mode, who in (("engine", "rccl", "engine API"), ("shim", "rccl", "shim-driven"), ("engine", "torch", "torch.distributed")):
+        p = subprocess.run([sys.executable, str(q.ROOT / "bench.py"), "--rows", "3000000", "--steps", "9", "--warmup", "2", "--reps", "3",
+                            "--no-extras", "--no-cpu-baseline", "--force-merge", "--exchange", mode, "--level", level],
                            capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
         assert p.returncode == 0, p.stderr[-3000:]
@@ -446,7 +448,10 @@ def test_bench_exchange_path_runs_on_one_gpu():
         assert len(lines) == 1, p.stdout[:2000]
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["steps"] == 9 and d["config"]["matches_total"] > 0
-        assert ("shim-driven" if mode == "rccl" else "torch.distributed") in d["config"]["parallelism"]
+        assert who in d["config"]["parallelism"], d["config"]["parallelism"]
+        assert d["config"]["level"] == ("engine" if (level, mode) == ("engine", "rccl") else "shim")
+        assert d["roofline"]["value_spread_reps"] == 3 and d["roofline"]["value_spread_min"] <= d["value"] <= d["roofline"]["value_spread_max"]
+        assert d["config"]["shim_ms_per_step"] is not None and "NOTE" not in d["config"]["parallelism"]
 
 
 @pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--query", "Q_A"]), (2, ["--mode", "count"])])

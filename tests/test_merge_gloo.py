@@ -8,6 +8,11 @@ the result must equal the whole-table oracle answer bit for bit.  Covers skewed 
 match while the others' none do), empty shards / empty results, a local buffer that is too small (reported),
 several queries in flight (begin k before finish k-1), and the all-or-none bring-up of the shim-driven
 exchange with a failure injected on one rank.
+
+Round 4: the payload travels in the COMPACT wire form wherever that is smaller (low 16 bits of every row number + one
+u32 per 65 536-row group; merge.wire_pack_numpy / wire_expand_numpy are the CPU twins of the shim's kernels) -- every
+case runs with it, a few-per-cent answer (Q_A, Q_B) and dense ones (risk_level > 1, every row) over shards of several
+groups included, and once more with u32 IDs only; the bytes that travelled are checked against the model.
 """
 import os
 import pathlib
@@ -35,14 +40,17 @@ WORKER = textwrap.dedent("""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cases = json.loads(os.environ["CASES"])
-    out = {}
+    compact = os.environ.get("COMPACT", "1") == "1"
+    out, wire = {}, {}
     for name, (n, chain, cap) in cases.items():
         start, count = mg.shard_rows(n, world, rank)
         host = q.HostSynth(count, seed=11, row0=start)
         local = host.oracle_scan(q.chain_from_jsonable(chain), id_base=start)
-        m = mg.IdMerger(torch, dist, world, rank, cap + 500 * rank if cap else count + 16, torch.device("cpu"))   # capacities differ by rank
+        m = mg.IdMerger(torch, dist, world, rank, cap + 500 * rank if cap else count + 16, torch.device("cpu"),
+                        shard=(count, start), compact=compact)                       # capacities differ by rank
         m.set_local(local)
         m.merge()
+        wire[name] = [m.wire_bytes_in, m.u32_bytes_in]
         try:
             out[name] = m.result().tolist()
             assert m.totals[0] == len(out[name]) and m.merged.numel() >= m.totals[0]
@@ -51,7 +59,7 @@ WORKER = textwrap.dedent("""
             out[name] = {"error": str(e), "held": m.merged[:m.totals[0]].numpy().view("uint32").tolist(), "caps": m.caps}
     # several queries in flight, as bench.py drives them: sizes of query k go out before the payload of k-1
     names = [k for k in cases if k != "overflow"]
-    ring = [mg.IdMerger(torch, dist, world, rank, 60_000, torch.device("cpu")) for _ in range(2)]
+    ring = [mg.IdMerger(torch, dist, world, rank, 120_000, torch.device("cpu"), shard=(0, 0), compact=compact) for _ in range(2)]
     piped = {}
     for i, name in enumerate(names):
         n, chain, _ = cases[name]
@@ -59,12 +67,14 @@ WORKER = textwrap.dedent("""
         m = ring[i % 2]
         if i >= 2:
             piped[names[i - 2]] = m.result().tolist()
+        m.shard = (count, start)                              # (the ring's mergers serve shards of different tables in turn)
         m.set_local(q.HostSynth(count, seed=11, row0=start).oracle_scan(q.chain_from_jsonable(chain), id_base=start))
         m.begin()
         ring[(i - 1) % 2].finish()
     for i in range(max(len(names) - 2, 0), len(names)):
         piped[names[i]] = ring[i % 2].result().tolist()
     assert piped == {k: out[k] for k in names}, "pipelined exchange differs"
+    out["_wire"] = wire
     if rank == world - 1:
         with open(os.environ["OUT_FILE"], "w") as f:           # (a pipe would fill up: the parent reads the ranks one by one)
             json.dump(out, f)
@@ -79,10 +89,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_merge_equals_whole_table(world, tmp_path):
+@pytest.mark.parametrize("world,compact", [(2, True), (3, True), (2, False)])
+def test_sharded_merge_equals_whole_table(world, compact, tmp_path):
     import json
     cases = {
+        # shards of two and more 65 536-row groups: the compact form's group offsets matter
+        "q_a_groups": (200_003, q.chain_to_jsonable([("risk_level", ">", "3")]), 0),
+        "q_b_groups": (200_003, q.chain_to_jsonable([("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")]), 0),
+        "r1_groups": (200_003, q.chain_to_jsonable([("risk_level", ">", "1")]), 0),
+        "s1_groups": (400_001, q.chain_to_jsonable([("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")]), 0),   # a few IDs per group
         "q_b": (50_001, q.chain_to_jsonable([("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "2")]), 8192),
         "s1": (50_001, q.chain_to_jsonable([("sudo_used", "=", "FALSE"), "AND", ("user_name", "=", "student1030")]), 4096),
         "none": (10_000, q.chain_to_jsonable([("risk_level", ">", "9")]), 4096),
@@ -99,14 +114,30 @@ def test_sharded_merge_equals_whole_table(world, tmp_path):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   CASES=json.dumps(cases), OMP_NUM_THREADS="1", OUT_FILE=str(tmp_path / "result.json"))
+                   CASES=json.dumps(cases), OMP_NUM_THREADS="1", OUT_FILE=str(tmp_path / "result.json"), COMPACT="1" if compact else "0")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     got = json.loads((tmp_path / "result.json").read_text())
+    mg = q.pq_merge()
     for name, (n, chain, cap) in cases.items():
         want = q.HostSynth(n, seed=11).oracle_scan(q.chain_from_jsonable(chain)).tolist()
+        # what the last rank took in: per peer the compact form where it is smaller, u32 IDs otherwise
+        model_wire = model_u32 = 0
+        for r in range(world - 1):
+            start, count = mg.shard_rows(n, world, r)
+            k = sum(1 for i in want if start <= i < start + count)
+            if cap:
+                k = min(k, cap + 500 * r + (cap + 500 * r) % 2)
+            model_u32 += 4 * k
+            model_wire += mg.wire_bytes(count, k) if (compact and mg.wire_pays(count, k)) else 4 * k
+        assert got["_wire"][name] == [model_wire, model_u32], (name, got["_wire"][name], model_wire, model_u32)
+        if compact and name in ("q_a_groups", "q_b_groups", "r1_groups", "all"):
+            assert model_wire < 0.6 * model_u32, name                 # about half the bytes
+        assert model_wire <= model_u32                                # never more than the IDs themselves
+        if name in ("s1", "tiny"):
+            assert model_wire == model_u32                            # a handful of IDs travel as they are
         if name == "overflow":
             assert "overflow" in got[name]["error"]
             caps = got[name]["caps"]
