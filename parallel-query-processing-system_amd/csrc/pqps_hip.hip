@@ -318,7 +318,7 @@ __global__ void warm_kernel() {}
 // host side of the shim
 // ---------------------------------------------------------------------------
 thread_local char g_err[512] = "";
-thread_local char g_kernel[160] = "";       // the instantiation the calling thread's last filter call launched (pqps_last_kernel)
+thread_local char g_kernel[200] = "";       // the instantiation the calling thread's last filter call launched (pqps_last_kernel)
 
 // host time spent waiting for a ring slot to become free again (as opposed to time inside runtime calls)
 uint64_t now_ns() {
