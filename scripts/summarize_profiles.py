@@ -36,13 +36,14 @@ def main():
     OUT.mkdir(exist_ok=True)
     for tag in tags:
         import os
+        name = tag if tag.startswith(rnd + "_") else f"{rnd}_{tag}"      # (tags may carry the round already: prof_r04_s1_100m)
         stats = glob.glob(str(ROOT / "gpurun_out" / f"prof_{tag}" / "**" / "*_kernel_stats.csv"), recursive=True)
         if stats:
-            shutil.copy(max(stats, key=os.path.getmtime), OUT / f"{rnd}_{tag}_kernel_stats.csv")
-            print("kernel stats ->", OUT / f"{rnd}_{tag}_kernel_stats.csv")
+            shutil.copy(max(stats, key=os.path.getmtime), OUT / f"{name}_kernel_stats.csv")
+            print("kernel stats ->", OUT / f"{name}_kernel_stats.csv")
         bench = ROOT / "gpurun_out" / f"prof_{tag}.json"
         if bench.exists():
-            shutil.copy(bench, OUT / f"{rnd}_{tag}_bench_under_rocprof.json")
+            shutil.copy(bench, OUT / f"{name}_bench_under_rocprof.json")
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         import os
         for d in glob.glob(str(ROOT / "gpurun_out" / f"pmc_{tag}_*")):
@@ -62,8 +63,8 @@ def main():
                     out[k]["hbm_read_bytes_per_launch"] = out[k]["FETCH_SIZE"]["avg_per_launch"] * 1024 * 2
                 if "WRITE_SIZE" in ctrs:
                     out[k]["hbm_write_bytes_per_launch"] = out[k]["WRITE_SIZE"]["avg_per_launch"] * 1024
-            (OUT / f"{rnd}_{tag}_pmc.json").write_text(json.dumps(out, indent=1, sort_keys=True))
-            print("pmc ->", OUT / f"{rnd}_{tag}_pmc.json")
+            (OUT / f"{name}_pmc.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+            print("pmc ->", OUT / f"{name}_pmc.json")
 
 
 if __name__ == "__main__":
