@@ -460,7 +460,7 @@ def main():
         """-> dict.  Every rank calls this."""
         slot_cap = (count + 4096) // 4096 * 4096 if (exchange and not count_mode) else \
             ((int(max_matches * 1.25) + 4096) // 4096 * 4096 if not count_mode else 4096)
-        native = exchange and args.exchange == "rccl" and args.backend == "nccl"
+        native = exchange and args.exchange == "rccl" and (args.backend == "nccl" or args.rccl_library is not None)
         qs = None
         if not exchange and not args.no_pipeline:
             qs = C.c_void_p()
@@ -704,7 +704,10 @@ def main():
 
     # ---- run the levels.  Engine level first (its engines are gone before the shim level allocates its buffers).
     eng = None
-    want_engine = args.level == "engine" and not args.no_pipeline and (not exchange or (args.exchange == "rccl" and args.backend == "nccl"))
+    # (the product drives RCCL itself whenever torch.distributed runs over it -- or over anything else when the host names the library
+    #  to load: the rehearsal of N > 1 on a one-GPU box uses gloo as torch's transport and tests/loopback/libloopback_mp.so as "RCCL")
+    product_rccl = args.exchange == "rccl" and (args.backend == "nccl" or args.rccl_library is not None)
+    want_engine = args.level == "engine" and not args.no_pipeline and (not exchange or product_rccl)
     if want_engine:
         err = None
         try:

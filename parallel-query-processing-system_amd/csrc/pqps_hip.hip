@@ -1691,9 +1691,13 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     X_TRY(hipMalloc((void **)&x->sizes_dev, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t)));
     X_TRY(hipHostMalloc((void **)&x->sizes_host, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t), hipHostMallocDefault));
     X_TRY(hipMalloc((void **)&x->totals, (size_t)ring * 2 * sizeof(uint64_t)));
-    X_TRY(hipMemset(x->local, 0, (size_t)ring * x->stride * 4));
-    X_TRY(hipMemset(x->hdr_dev, 0, (size_t)ring * kWireHeaderWords * sizeof(uint64_t)));
-    X_TRY(hipMemset(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t)));
+    // (on the exchange's own stream and awaited below: a fill on the null stream is not ordered against this non-blocking stream,
+    //  and the first thing connect puts on it is this rank's capacity INTO `local` -- found by the process-loopback rehearsal,
+    //  where one rank of three announced a capacity of 0)
+    X_TRY(hipMemsetAsync(x->local, 0, (size_t)ring * x->stride * 4, x->stream));
+    X_TRY(hipMemsetAsync(x->hdr_dev, 0, (size_t)ring * kWireHeaderWords * sizeof(uint64_t), x->stream));
+    X_TRY(hipMemsetAsync(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t), x->stream));
+    X_TRY(hipStreamSynchronize(x->stream));
     memset(x->sizes_host, 0, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t));
     x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->sizes_done = new hipEvent_t[ring]();
     x->merge_done = new hipEvent_t[ring]();

@@ -480,6 +480,40 @@ def test_bench_with_several_ranks_sharing_the_gpu(ranks, extra):
     assert d["config"]["matches_total"] > 0 and d["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("ranks,extra,level", [(2, [], "engine"), (3, ["--query", "Q_A"], "engine"), (2, ["--mode", "count"], "engine"),
+                                               (2, ["--query", "Q_A", "--level", "shim"], "shim")])
+def test_bench_engine_level_with_several_ranks_through_the_process_loopback(ranks, extra, level):
+    """bench.py exactly as the driver launches it for N > 1 -- torch.distributed.run, one process per rank, `value` at the ENGINE
+    level: rank engines (initializeEngineSyntheticRankHIP) joined through hipEngineJoinRanksHIP, tickets issued by the C loop,
+    every answer the whole table's -- on this box's one GPU: torch's transport is gloo and the "RCCL" the product loads is
+    tests/loopback/libloopback_mp.so (ranks as processes, data through shared memory).  Also once at the shim level
+    (pqps_exchange_* from Python).  bench.py verifies count + checksum on every rank before and after timing and exits non-zero
+    on a wrong answer; the record must say which path ran."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    lib = q.ROOT / "tests" / "loopback" / "libloopback_mp.so"
+    assert lib.exists(), "build it first: make -C tests/loopback"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(q.ROOT / "bench.py"),
+                        "--gpus", str(ranks), "--backend", "gloo", "--exchange", "rccl", "--rccl-library", str(lib),
+                        "--rows", "2000003", "--steps", "12", "--warmup", "3", "--reps", "2", "--no-extras", "--no-cpu-baseline", *extra],
+                       capture_output=True, text=True, timeout=900, cwd=str(q.ROOT), env=dict(os.environ, LOOPBACK_MP_OUTBOX_MB="64"))
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["config"]["rows_total"] == 2000003 * ranks and d["config"]["matches_total"] > 0
+    assert d["config"]["level"] == level and "NOTE" not in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert ("engine API" if level == "engine" else "shim-driven") in d["config"]["parallelism"]
+    if "Q_A" in extra:
+        assert "bytes on the wire" in d["config"]["parallelism"]               # the compact form's accounting made it into the record
+
+
 def test_flags_mode(ctx):
     n = 70_001
     dev = pq.SyntheticTable(ctx, n, seed=9)
