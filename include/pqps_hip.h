@@ -313,9 +313,11 @@ int pqps_qstream_kernel_time(pqps_qstream *q, double *eval_ms, double *total_ms,
  * ncclAllGather, the payload as ONE group of ncclSend / ncclRecv of exactly count[r] IDs between every pair of
  * ranks, landing at its displacement -- nothing padded on the wire, no compaction pass, and no receive buffer
  * that could be too small (the gathered list is grown to the sizes before the payload moves).
- * WIRE FORM.  An answer of more than ~2 matches per 65 536 rows travels in compact form: the low 16 bits of every row number
+ * WIRE FORM.  An answer of 32 768 matches and more (below that latency, not bytes, is the cost -- PQPS_WIRE_MIN_IDS moves the
+ * floor) and of more than ~2 matches per 65 536 rows travels in compact form: the low 16 bits of every row number
  * (relative to the shard's first row) + one u32 per 65 536-row group saying where the group's entries begin -- 2 bytes per
- * match + 4 per group instead of 4 per match; the receiving GPU rebuilds the u32 IDs at the displacement (a copy kernel).
+ * match + 4 per group instead of 4 per match; the receiving GPU rebuilds the u32 IDs at the displacement (one copy kernel
+ * for all the peers of a query).
  * The sender decides from its own count; the 32-byte-per-rank sizes all-gather carries (reported count, rows, first row,
  * form), so every receiver sizes its receives alike.  PQPS_EXCHANGE_COMPACT=0: always u32 (A/B runs, tests).
  * BOUNDED WAITS.  Every host wait of the exchange (a ring slot, the sizes, a result, pqps_exchange_sync) ends after
@@ -371,7 +373,7 @@ uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset);
 /* The compact wire form by itself, for a host that moves the payload with its own collectives (merge.py over
  * torch.distributed): pqps_wire_pack reads a slot as the filter left it ([u64 count][u64][u32 IDs ...], `capacity` IDs), writes
  * this rank's four header words (reported count, rows, first row, form: 1 = compact) to header_dev and -- if `enabled` and
- * the compact form is smaller (pqps_wire_pays) -- the payload [u32 goff[groups + 1], padded to 16 bytes][u16 low[n]] to
+ * the compact form pays (pqps_wire_pays: >= 32 768 IDs and fewer bytes) -- the payload [u32 goff[groups + 1], padded to 16 bytes][u16 low[n]] to
  * `wire` (room for pqps_wire_bytes(n_rows, min(capacity, n_rows))); pqps_wire_expand turns a received payload into u32 IDs
  * at out_ids (the list's displacement in the gathered list). */
 uint64_t pqps_wire_bytes(uint64_t n_rows, uint64_t n_ids);

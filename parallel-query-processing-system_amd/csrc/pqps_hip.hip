@@ -179,14 +179,17 @@ constexpr uint64_t kWireHeaderWords = 4;                            // u64 per r
 __host__ __device__ inline uint64_t wire_groups(uint64_t n_rows) { return (n_rows + kWireGroupRows - 1) / kWireGroupRows; }
 __host__ __device__ inline uint64_t wire_goff_bytes(uint64_t n_rows) { return ((wire_groups(n_rows) + 1) * 4 + 15) & ~15ull; }
 __host__ __device__ inline uint64_t wire_bytes(uint64_t n_rows, uint64_t n) { return wire_goff_bytes(n_rows) + ((n * 2 + 3) & ~3ull); }
-__host__ __device__ inline bool wire_pays(uint64_t n_rows, uint64_t n) { return wire_bytes(n_rows, n) < n * 4; }
+// ... and only a list of some size is worth the two extra launches (pack here, rebuild there): below kWireMinIds IDs (128 KB as
+// u32: latency, not bytes, is what such a payload costs) it travels as it is.  PQPS_WIRE_MIN_IDS: the tests set 0.
+constexpr uint64_t kWireMinIds = 32768;
+__host__ __device__ inline bool wire_pays(uint64_t n_rows, uint64_t n, uint64_t min_ids) { return n >= min_ids && wire_bytes(n_rows, n) < n * 4; }
 
 // slot = [u64 reported count][u64][u32 IDs ...] as the filter left it; hdr = this rank's 4 words of the sizes all-gather
 __global__ __launch_bounds__(256) void wire_pack_kernel(const uint32_t *slot, uint64_t cap, uint64_t n_rows, uint32_t id_base, int enabled,
-                                                        uint64_t *hdr, uint8_t *wire) {
+                                                        uint64_t min_ids, uint64_t *hdr, uint8_t *wire) {
     const uint64_t reported = *(const uint64_t *)slot;
     const uint64_t n = reported < cap ? reported : cap;            // a slot that overflowed holds (and sends) `cap` IDs
-    const bool compact = enabled && wire_pays(n_rows, n);
+    const bool compact = enabled && wire_pays(n_rows, n, min_ids);
     if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = reported; hdr[1] = n_rows; hdr[2] = id_base; hdr[3] = compact ? 1u : 0u; }
     if (!compact) return;
     const uint32_t *ids = slot + kSlotHeaderWords;
@@ -214,6 +217,24 @@ __global__ __launch_bounds__(256) void wire_expand_kernel(const uint8_t *wire, u
     for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
         const uint32_t b = goff[g], e = goff[g + 1], base = id_base + (uint32_t)(g * kWireGroupRows);
         for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) out[i] = base + (uint32_t)low[i];
+    }
+}
+
+// the same for every peer's payload of one query in ONE launch (blockIdx.y = peer): seven launches of a few microseconds each
+// would sit in the exchange stream behind one another for an 8-rank world
+constexpr uint32_t kWireManyPeers = 16;
+struct WireExpandMany {
+    uint32_t n;
+    struct { const uint8_t *wire; uint64_t rows; uint32_t *out; uint32_t id_base; uint32_t pad; } p[kWireManyPeers];
+};
+__global__ __launch_bounds__(256) void wire_expand_many_kernel(const WireExpandMany m) {
+    const auto &d = m.p[blockIdx.y];
+    const uint32_t *goff = (const uint32_t *)d.wire;
+    const uint16_t *low = (const uint16_t *)(d.wire + wire_goff_bytes(d.rows));
+    const uint64_t groups = wire_groups(d.rows);
+    for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const uint32_t b = goff[g], e = goff[g + 1], base = d.id_base + (uint32_t)(g * kWireGroupRows);
+        for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) d.out[i] = base + (uint32_t)low[i];
     }
 }
 
@@ -337,6 +358,11 @@ inline const char *tuning_env(const char *name) {
     (void)name;
     return nullptr;
 #endif
+}
+
+uint64_t wire_min_ids() {
+    const char *e = getenv("PQPS_WIRE_MIN_IDS");       // read per call: one process may hold test cases with and without it
+    return e ? strtoull(e, nullptr, 10) : (uint64_t)kWireMinIds;
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -1848,20 +1874,34 @@ int exchange_payload(pqps_exchange *x, uint32_t slot) {
     }
     if (x->world > 1) { const int end = x->rccl.GroupEnd(); if (!nrc) nrc = end; }
     if (nrc) return fail(PQPS_EHIP, "ncclSend / ncclRecv: %s", x->rccl.GetErrorString(nrc));
-    // the peers' compact payloads become row IDs at their displacements
+    // the peers' compact payloads become row IDs at their displacements: one launch for up to kWireManyPeers of them
     displ = 0; at = 0;
+    WireExpandMany many;
+    many.n = 0;
+    uint64_t most_groups = 0;
+    auto flush = [&]() -> int {
+        if (many.n == 0) return PQPS_OK;
+        const uint64_t max_blocks = (uint64_t)x->ctx->compute_units * 8 / many.n + 1;
+        const uint64_t bx = most_groups < max_blocks ? most_groups : max_blocks;
+        hipLaunchKernelGGL(wire_expand_many_kernel, dim3((uint32_t)(bx ? bx : 1), many.n), dim3(256), 0, x->stream, many);
+        HIP_TRY(hipGetLastError());
+        many.n = 0;
+        most_groups = 0;
+        return PQPS_OK;
+    };
     for (uint32_t r = 0; r < x->world; r++) {
         const uint64_t k = held(r);
         if (r != x->rank && k && hdr[r * kWireHeaderWords + 3]) {
             const uint64_t rows = hdr[r * kWireHeaderWords + 1], groups = wire_groups(rows);
-            const uint64_t max_blocks = (uint64_t)x->ctx->compute_units * 8;
-            hipLaunchKernelGGL(wire_expand_kernel, dim3((uint32_t)(groups < max_blocks ? groups : max_blocks)), dim3(256), 0, x->stream,
-                               x->wire_in[slot] + at, rows, (uint32_t)hdr[r * kWireHeaderWords + 2], merged + displ);
-            HIP_TRY(hipGetLastError());
+            auto &d = many.p[many.n++];
+            d.wire = x->wire_in[slot] + at; d.rows = rows; d.out = merged + displ; d.id_base = (uint32_t)hdr[r * kWireHeaderWords + 2]; d.pad = 0;
+            if (groups > most_groups) most_groups = groups;
             at += (wire_bytes(rows, k) + 15) & ~15ull;
+            if (many.n == kWireManyPeers) { const int frc = flush(); if (frc) return frc; }
         }
         displ += k;
     }
+    { const int frc = flush(); if (frc) return frc; }
     x->totals_host[2 * slot] = total;
     x->totals_host[2 * slot + 1] = reported;
     HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
@@ -2008,7 +2048,7 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks == 0) blocks = 1;
         hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, x->stream, local, x->cap, n_rows, id_base, compact ? 1 : 0,
-                           hdr_dev, x->wire_out[slot]);
+                           wire_min_ids(), hdr_dev, x->wire_out[slot]);
         HIP_TRY(hipGetLastError());
         int nrc = x->rccl.AllGather(hdr_dev, sizes_dev, kWireHeaderWords, kRcclUint64, x->comm, x->stream);
         if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
@@ -2099,7 +2139,7 @@ uint64_t pqps_exchange_wait_ns(pqps_exchange *x, int reset) {
 
 // The compact wire form for a host that drives the exchange itself (merge.py over torch.distributed): the same two kernels.
 uint64_t pqps_wire_bytes(uint64_t n_rows, uint64_t n_ids) { return wire_bytes(n_rows, n_ids); }
-int pqps_wire_pays(uint64_t n_rows, uint64_t n_ids) { return wire_pays(n_rows, n_ids) ? 1 : 0; }
+int pqps_wire_pays(uint64_t n_rows, uint64_t n_ids) { return wire_pays(n_rows, n_ids, wire_min_ids()) ? 1 : 0; }
 
 int pqps_wire_pack(pqps_ctx *ctx, const uint32_t *slot, uint64_t capacity, uint64_t n_rows, uint32_t id_base, int enabled,
                    uint64_t *header_dev, void *wire, void *stream) {
@@ -2110,7 +2150,7 @@ int pqps_wire_pack(pqps_ctx *ctx, const uint32_t *slot, uint64_t capacity, uint6
     const uint64_t max_blocks = (uint64_t)ctx->compute_units * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, slot, capacity, n_rows, id_base, enabled ? 1 : 0, header_dev, (uint8_t *)wire);
+    hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, slot, capacity, n_rows, id_base, enabled ? 1 : 0, wire_min_ids(), header_dev, (uint8_t *)wire);
     HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }

@@ -64,8 +64,13 @@ def wire_bytes(n_rows, n_ids):
     return wire_goff_bytes(n_rows) + ((n_ids * 2 + 3) & ~3)
 
 
+WIRE_MIN_IDS = 32768      # below this many IDs a list travels as it is: latency, not bytes, is what it costs (PQPS_WIRE_MIN_IDS: tests set 0)
+
+
 def wire_pays(n_rows, n_ids):
-    return wire_bytes(n_rows, n_ids) < 4 * n_ids
+    import os
+    floor = int(os.environ.get("PQPS_WIRE_MIN_IDS", WIRE_MIN_IDS))
+    return n_ids >= floor and wire_bytes(n_rows, n_ids) < 4 * n_ids
 
 
 def wire_pack_numpy(ids_u32, n_rows, id_base):

@@ -16,6 +16,18 @@ import pytest
 
 import qpelib as q
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _compact_lists_of_any_size():
+    """The product keeps lists below 32 768 IDs as u32 on the wire; these cases want the compact form at test sizes (the workers inherit it)."""
+    old = os.environ.get("PQPS_WIRE_MIN_IDS")
+    os.environ["PQPS_WIRE_MIN_IDS"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("PQPS_WIRE_MIN_IDS", None)
+    else:
+        os.environ["PQPS_WIRE_MIN_IDS"] = old
+
 pq = q.pq
 pytestmark = pytest.mark.gpu
 LOOPBACK = q.ROOT / "tests" / "loopback" / "libloopback_rccl.so"

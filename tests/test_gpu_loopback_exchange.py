@@ -26,6 +26,18 @@ import pytest
 
 import qpelib as q
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _compact_lists_of_any_size():
+    """The product keeps lists below 32 768 IDs as u32 on the wire; these cases want the compact form at test sizes (the workers inherit it)."""
+    old = os.environ.get("PQPS_WIRE_MIN_IDS")
+    os.environ["PQPS_WIRE_MIN_IDS"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("PQPS_WIRE_MIN_IDS", None)
+    else:
+        os.environ["PQPS_WIRE_MIN_IDS"] = old
+
 pq = q.pq
 pytestmark = pytest.mark.gpu
 
@@ -126,8 +138,11 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("world,compact", [(2, True), (3, True), (2, False)])
-def test_exchange_world_of_several_through_the_loopback(tmp_path, world, compact):
+@pytest.mark.parametrize("world,compact,floor", [(2, True, "0"), (3, True, "0"), (2, False, "0"), (2, True, None)])
+def test_exchange_world_of_several_through_the_loopback(tmp_path, monkeypatch, world, compact, floor):
+    # floor None: the product's own rule -- only lists of 32 768 IDs and more travel compact (s1_sparse does not)
+    if floor is None:
+        monkeypatch.delenv("PQPS_WIRE_MIN_IDS")
     assert LOOPBACK.exists(), "build it first: make -C tests/loopback (python __graft_entry__.py does)"
     cases = {k: (v[0], q.chain_to_jsonable(v[1]), v[2], v[3], v[4]) for k, v in CASES.items()}
     script = tmp_path / "worker.py"
@@ -160,7 +175,9 @@ def test_exchange_world_of_several_through_the_loopback(tmp_path, world, compact
                 in_wire += mg.wire_bytes(pc, k) if (compact and mg.wire_pays(pc, k)) else 4 * k
             assert wire[1:] == [selects * in_wire, selects * in_u32], (name, r, wire, selects, in_wire, in_u32)
             if compact and name in ("q_a_compact", "r1_dense", "dense_grows", "q_b_ring6") and in_u32:
-                assert in_wire < 0.55 * in_u32, (name, in_wire, in_u32)
+                assert in_wire < 0.55 * in_u32, (name, in_wire, in_u32)      # 66 000 IDs and more per rank: above the floor too
+            if floor is None and name == "s1_sparse":
+                assert in_wire == in_u32, (name, in_wire, in_u32)            # below the floor: as they are
             assert len(results) == sum(1 for s in plan if s[0] in "rk"), (name, r)
             for entry in results:
                 if name == "overflow":

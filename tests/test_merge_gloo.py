@@ -26,6 +26,18 @@ import pytest
 
 import qpelib as q
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _compact_lists_of_any_size():
+    """The product keeps lists below 32 768 IDs as u32 on the wire; these cases want the compact form at test sizes (the workers inherit it)."""
+    old = os.environ.get("PQPS_WIRE_MIN_IDS")
+    os.environ["PQPS_WIRE_MIN_IDS"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("PQPS_WIRE_MIN_IDS", None)
+    else:
+        os.environ["PQPS_WIRE_MIN_IDS"] = old
+
 ROOT = q.ROOT
 
 WORKER = textwrap.dedent("""
@@ -149,6 +161,19 @@ def test_sharded_merge_equals_whole_table(world, compact, tmp_path):
             assert got[name]["held"] == held
         else:
             assert got[name] == want, name
+
+
+def test_wire_floor_keeps_small_lists_as_they_are(monkeypatch):
+    """Below 32 768 IDs a list travels as u32 whatever its density; PQPS_WIRE_MIN_IDS moves the floor (csrc/pqps_hip.hip: wire_pays)."""
+    mg = q.pq_merge()
+    monkeypatch.delenv("PQPS_WIRE_MIN_IDS", raising=False)
+    rows = 4 * 65536
+    assert not mg.wire_pays(rows, 32767) and mg.wire_pays(rows, 32768)
+    assert not mg.wire_pays(1 << 30, 32768)                            # 2 IDs per group: the offsets cost more than they save
+    monkeypatch.setenv("PQPS_WIRE_MIN_IDS", "0")
+    assert mg.wire_pays(rows, 100) and not mg.wire_pays(rows, 3)
+    monkeypatch.setenv("PQPS_WIRE_MIN_IDS", "1000000")
+    assert not mg.wire_pays(rows, 200000)
 
 
 BRINGUP_WORKER = textwrap.dedent("""
