@@ -429,6 +429,7 @@ def main():
                     kern_ms += tot.value
                     launches += k.value
             wire = [sum(x) for x in zip(*[e.wire_bytes() for e in engines])]
+            eager = [e.eager_queries() for e in engines]
             n_q = args.steps * max(1, args.reps) * args.engine_threads
             n_issued = n_q + (args.warmup + 2 * (max(1, args.reps) - 1)) * args.engine_threads + copies     # timed + warm-up + verification queries
             med = sorted(regions)[len(regions) // 2]
@@ -439,6 +440,7 @@ def main():
                    "host_issue_us_per_query": issue_s / n_q * 1e6, "host_await_us_per_query": await_s / n_q * 1e6,
                    "in_stream_kernel_ms": kern_ms / max(launches, 1), "launches_timed": launches,
                    "wire_bytes_in_per_query": wire[0] / n_issued, "u32_bytes_in_per_query": wire[1] / n_issued,
+                   "one_collective_queries": sum(x[0] for x in eager), "exchanged_queries": sum(x[1] for x in eager), "eager_ids_per_rank": eager[0][2],
                    "verified": "every engine's answer before the timed regions and the last ticket of every timed region: count and "
                                "device-side checksum of the list == the ranks' shim-level lists in rank order",
                    "api": ("initializeEngineSyntheticRankHIP + hipEngineJoinRanksHIP + " if exchange else "initializeEngineSyntheticHIP + ")
@@ -659,7 +661,7 @@ def main():
             sys.exit("bench: the timed steps left a wrong answer: " + (why or "on another rank"))
         waited = 0.0
         in_stream_ms = None
-        wire = None
+        wire = eager = None
         if qs is not None:
             waited = L.pqps_qstream_wait_ns(qs, 1) * 1e-9
             ev, tot, k = C.c_double(), C.c_double(), C.c_int()
@@ -671,6 +673,9 @@ def main():
             wb = (C.c_uint64 * 2)()
             L.pqps_exchange_wire_bytes(st["xch"].h, wb, 0)
             wire = (int(wb[0]), int(wb[1]))
+            eg = (C.c_uint64 * 3)()
+            L.pqps_exchange_eager(st["xch"].h, eg, 0)
+            eager = (int(eg[0]), int(eg[1]), int(eg[2]))
         elif exchange and not count_mode:
             wire = (sum(m.wire_bytes_in for m in st["mergers"]), sum(m.u32_bytes_in for m in st["mergers"]))
         n_steps_all = args.steps * len(regions)
@@ -692,6 +697,8 @@ def main():
                "avg_kernel_ms": kern_ms / max(launches, 1), "avg_pipeline_ms": pipe_ms / max(launches, 1), "launches_timed": launches,
                "in_stream_kernel_ms": in_stream_ms, "native": st["native"], "pipelined": qs is not None or st["native"],
                "wire_bytes_in_per_step": wire[0] / n_steps_all if wire else None, "u32_bytes_in_per_step": wire[1] / n_steps_all if wire else None,
+               "one_collective_queries": eager[0] if eager else None, "exchanged_queries": eager[1] if eager else None,
+               "eager_ids_per_rank": eager[2] if eager else None,
                "api": ("pqps_exchange_%s" % ("count" if count_mode else "select") if st["native"] else
                        ("pqps_qstream_%s" % ("count" if count_mode else "scan") if qs is not None else
                         "pqps_filter_%s%s" % ("count" if count_mode else "scan", " + torch.distributed (IdMerger)" if exchange else "")))
@@ -751,11 +758,15 @@ def main():
     if exchange:
         parallelism += (f", one {'RCCL' if args.backend == 'nccl' else args.backend + ' (host-staged rehearsal)'} "
                         + ("all-reduce of the counts" if count_mode else
-                           "all-gatherv of the row IDs per query on every rank (32-byte-per-rank sizes all-gather, then exactly-sized send/recv at "
-                           "displacements; a list of more than ~2 IDs per 65 536 rows travels in compact form: 2 bytes per ID + 4 per group)")
+                           "all-gatherv of the row IDs per query on every rank (sizes all-gather with room for 16 384 IDs per rank: an answer "
+                           "that fits arrives in that ONE collective; otherwise exactly-sized send/recv at displacements, a list of 32 768 IDs "
+                           "and more in compact form: 2 bytes per ID + 4 per 65 536-row group)")
                         + f", {via}")
         if wire_in is not None and not count_mode:
             parallelism += f"; payload received per query and rank: {wire_in:,.0f} bytes on the wire for {u32_in:,.0f} bytes of u32 IDs"
+            src = eng if eng is not None else (shim or {})
+            if src.get("exchanged_queries"):
+                parallelism += f"; {src['one_collective_queries']} of {src['exchanged_queries']} exchanged queries finished in the one collective"
     if result_notes:
         parallelism += "; NOTE: " + "; ".join(result_notes)
     result = {

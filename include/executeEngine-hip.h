@@ -188,6 +188,9 @@ int hipEngineJoinConnectHIP(struct engineS *engine, const void *id128);
 int hipEngineLeaveRanksHIP(struct engineS *engine);
 /* payload bytes this rank has received: out[0] as they travelled, out[1] as u32 row numbers would have */
 int hipEngineWireBytesHIP(struct engineS *engine, unsigned long long out[2], int reset);
+/* out[0] = SELECTs whose answer arrived with the sizes (one collective, pqps_exchange_eager), out[1] = SELECTs finished,
+ * out[2] = row numbers a rank's block has room for (0: off) */
+int hipEngineEagerQueriesHIP(struct engineS *engine, unsigned long long out[3], int reset);
 
 /* Device time of the engine's queries AS THEY RUN on the lanes (several in flight): the recorders of the shards' query
  * streams (pqps_qstream_set_timing), events on the dispatch packets.  hipEngineKernelTime sums over the launches

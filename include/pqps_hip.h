@@ -384,6 +384,15 @@ int pqps_wire_expand(pqps_ctx *ctx, const void *wire, uint64_t n_rows, uint32_t 
 /* Payload bytes this rank has RECEIVED from its peers so far: out[0] as they travelled (compact or u32), out[1] what the
  * same lists are as u32 IDs; `reset` != 0 clears both. */
 void pqps_exchange_wire_bytes(pqps_exchange *x, uint64_t out[2], int reset);
+/* SMALL ANSWERS IN ONE COLLECTIVE.  Behind each rank's 32-byte header the sizes all-gather of a SELECT has room for
+ * PQPS_EXCHANGE_EAGER_IDS row numbers (default 16 384 = 64 KB per rank; 0: none; the smallest setting and the smallest slot of
+ * the world win, agreed at connect; at most 4 MB gathered per query): a rank whose list fits puts it there, and when EVERY
+ * rank's list fits the answer is complete after that one all-gather and one copy kernel -- no send / recv group, no size on
+ * the host first.  When a list does not fit the query takes the two steps described above, and the next SELECT gathers bare
+ * headers again until an answer that would have fitted has been seen (every rank reads the same sizes at the same point of its
+ * call sequence, so all take the same turn).  out[0] = SELECTs that finished in the one collective, out[1] = SELECTs
+ * finished, out[2] = the room agreed on (IDs per rank; 0 = off). */
+void pqps_exchange_eager(pqps_exchange *x, uint64_t out[3], int reset);
 int pqps_exchange_destroy(pqps_exchange *x);
 
 /* Checksums of a device-resident ID list: out[0] = sum of ids[i], out[1] = sum of ids[i] * (2 i + 1), both mod 2^64 (the

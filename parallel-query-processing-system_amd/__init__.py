@@ -333,6 +333,8 @@ def lib():
     L.pqps_wire_pack.argtypes = [vp, vp, u64, u64, u32, C.c_int, vp, vp, vp]
     L.pqps_wire_expand.argtypes = [vp, vp, u64, u32, vp, vp]
     L.pqps_exchange_wire_bytes.restype = None
+    L.pqps_exchange_eager.argtypes = [vp, C.POINTER(u64), C.c_int]
+    L.pqps_exchange_eager.restype = None
     L.pqps_exchange_destroy.argtypes = [vp]
     L.hipCompileWhere.argtypes = [C.POINTER(Schema), W, C.POINTER(Predicate), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
     L.hipCompileWherePlan.argtypes = [C.POINTER(Schema), W, C.POINTER(Plan), C.c_char_p, C.c_size_t]
@@ -370,6 +372,7 @@ def lib():
     L.hipEngineJoinConnectHIP.argtypes = [E, vp]
     L.hipEngineLeaveRanksHIP.argtypes = [E]
     L.hipEngineWireBytesHIP.argtypes = [E, C.POINTER(C.c_ulonglong), C.c_int]
+    L.hipEngineEagerQueriesHIP.argtypes = [E, C.POINTER(C.c_ulonglong), C.c_int]
     L.hipQueryChecksumHIP.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.pqps_ids_checksum.argtypes = [vp, vp, u64, C.POINTER(u64), vp]
     L.pqps_qstream_reserve.argtypes = [vp, u64]
@@ -690,6 +693,12 @@ class HipEngine:
         out = (C.c_ulonglong * 2)()
         lib().hipEngineWireBytesHIP(self.e, out, 1 if reset else 0)
         return int(out[0]), int(out[1])
+
+    def eager_queries(self, reset=False):
+        """(SELECTs answered in the sizes all-gather alone, SELECTs finished, IDs a rank's block has room for) of this rank's exchange."""
+        out = (C.c_ulonglong * 3)()
+        lib().hipEngineEagerQueriesHIP(self.e, out, 1 if reset else 0)
+        return int(out[0]), int(out[1]), int(out[2])
 
     def ticket_checksum(self, ticket):
         """(sum of the row numbers, sum of id[i] * (2 i + 1)) mod 2^64 of the ticket's answer, computed on the device."""

@@ -184,13 +184,21 @@ __host__ __device__ inline uint64_t wire_bytes(uint64_t n_rows, uint64_t n) { re
 constexpr uint64_t kWireMinIds = 32768;
 __host__ __device__ inline bool wire_pays(uint64_t n_rows, uint64_t n, uint64_t min_ids) { return n >= min_ids && wire_bytes(n_rows, n) < n * 4; }
 
-// slot = [u64 reported count][u64][u32 IDs ...] as the filter left it; hdr = this rank's 4 words of the sizes all-gather
+// slot = [u64 reported count][u64][u32 IDs ...] as the filter left it; hdr = this rank's 4 words of the sizes all-gather.
+// eager_ids != 0: hdr is the head of this rank's block of an EAGER all-gather (below) -- a list of up to eager_ids IDs goes into the
+// block behind the header as it is, and the query needs no second step if every rank's list fits.
 __global__ __launch_bounds__(256) void wire_pack_kernel(const uint32_t *slot, uint64_t cap, uint64_t n_rows, uint32_t id_base, int enabled,
-                                                        uint64_t min_ids, uint64_t *hdr, uint8_t *wire) {
+                                                        uint64_t min_ids, uint64_t *hdr, uint8_t *wire, uint64_t eager_ids, uint32_t *eager_dst) {
     const uint64_t reported = *(const uint64_t *)slot;
     const uint64_t n = reported < cap ? reported : cap;            // a slot that overflowed holds (and sends) `cap` IDs
-    const bool compact = enabled && wire_pays(n_rows, n, min_ids);
+    const bool eager = eager_ids && reported <= eager_ids;
+    const bool compact = !eager && enabled && wire_pays(n_rows, n, min_ids);
     if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = reported; hdr[1] = n_rows; hdr[2] = id_base; hdr[3] = compact ? 1u : 0u; }
+    if (eager) {
+        const uint32_t *ids = slot + kSlotHeaderWords;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) eager_dst[i] = ids[i];
+        return;
+    }
     if (!compact) return;
     const uint32_t *ids = slot + kSlotHeaderWords;
     uint32_t *goff = (uint32_t *)wire;
@@ -236,6 +244,43 @@ __global__ __launch_bounds__(256) void wire_expand_many_kernel(const WireExpandM
         const uint32_t b = goff[g], e = goff[g + 1], base = d.id_base + (uint32_t)(g * kWireGroupRows);
         for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) d.out[i] = base + (uint32_t)low[i];
     }
+}
+
+// ---- small answers in ONE collective --------------------------------------------------------------------------------------
+// The sizes all-gather of a query carries, behind each rank's 32-byte header, room for eager_ids IDs: a rank whose list fits puts it
+// there.  If EVERY rank's list fits (S1 at 125 M rows per rank: 8 400 IDs) the gathered blocks hold the whole answer -- this kernel
+// moves each rank's IDs to its displacement (prefix of the gathered counts, mpi:758-762, computed here by every workgroup) and the
+// query is done without the host having seen a size: no send / recv group (14 calls and tens of microseconds of host time at
+// 8 ranks), no second wait.  If one rank's list does not fit, this kernel only lays the headers out for the host and the query takes
+// the two-step path.   gathered = [world][block_bytes]: [u64 count, rows, id_base, form][u32 ids[eager_ids]]
+constexpr uint64_t kEagerIdsDefault = 16384;
+__global__ __launch_bounds__(256) void eager_unpack_kernel(const uint8_t *gathered, uint32_t world, uint64_t block_bytes, uint64_t eager_ids,
+                                                           const uint64_t *caps, uint32_t *merged, uint64_t *sizes) {
+    __shared__ uint64_t s_before[256];
+    __shared__ uint32_t s_big[256];
+    const uint32_t r = blockIdx.y;
+    uint64_t before = 0;
+    uint32_t big = 0;
+    for (uint32_t q = threadIdx.x; q < world; q += blockDim.x) {
+        const uint64_t *h = (const uint64_t *)(gathered + (uint64_t)q * block_bytes);
+        const uint64_t c = h[0], held = c < caps[q] ? c : caps[q];
+        if (c > eager_ids) big = 1;
+        if (q < r) before += held;
+        if (r == 0 && blockIdx.x == 0) for (uint32_t w = 0; w < kWireHeaderWords; w++) sizes[(uint64_t)q * kWireHeaderWords + w] = h[w];
+    }
+    s_before[threadIdx.x] = before;
+    s_big[threadIdx.x] = big;
+    __syncthreads();
+    for (uint32_t step = blockDim.x / 2; step; step >>= 1) {
+        if (threadIdx.x < step) { s_before[threadIdx.x] += s_before[threadIdx.x + step]; s_big[threadIdx.x] |= s_big[threadIdx.x + step]; }
+        __syncthreads();
+    }
+    if (s_big[0]) return;                                            // somebody's list is elsewhere: the two-step path moves them all
+    const uint64_t *h = (const uint64_t *)(gathered + (uint64_t)r * block_bytes);
+    const uint64_t k = h[0] < caps[r] ? h[0] : caps[r];
+    const uint32_t *src = (const uint32_t *)(h + kWireHeaderWords);
+    uint32_t *dst = merged + s_before[0];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < k; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 // ---- DELETE support: keep-list gather ------------------------------------------------------------
@@ -1646,6 +1691,13 @@ struct pqps_exchange {
     uint64_t sizes_wait_ns;          // host time spent waiting for the sizes of a query
     bool compact;                    // answers that gain from it travel in compact form (PQPS_EXCHANGE_COMPACT=0: always u32)
     uint64_t wire_bytes_in, u32_bytes_in;    // payload this rank has received: as it travelled / as u32 IDs would have
+    uint64_t eager_want, eager_ids;  // IDs a rank's block of the sizes all-gather has room for (PQPS_EXCHANGE_EAGER_IDS; 0: none), as agreed at connect
+    uint64_t eager_block;            // bytes of such a block: header + eager_ids IDs
+    uint8_t *eager_out, *eager_in;   // [ring][block] this rank's block, [ring][world][block] the gathered ones
+    uint64_t *caps_dev;              // [world] `caps` for the unpack kernel
+    bool eager_next;                 // the next SELECT gathers eager blocks: the last answer whose sizes were read fitted (every rank sees the same)
+    bool *eager_slot;                // [ring] the slot's query did
+    uint64_t eager_queries, select_queries;   // SELECTs finished in the sizes all-gather alone / SELECTs finished
     double timeout_s;                // bound of every host wait of the exchange (PQPS_EXCHANGE_TIMEOUT_S, default 30; 0: none)
     bool dead;                       // a wait ran out (or a rank could not receive): the communicator is aborted, every call fails
 };
@@ -1684,6 +1736,10 @@ int pqps_exchange_destroy(pqps_exchange *x) {
     delete[] x->state; delete[] x->issued; delete[] x->merged; delete[] x->merged_cap; delete[] x->totals_host; delete[] x->caps;
     delete[] x->wire_out; delete[] x->wire_out_cap; delete[] x->wire_in; delete[] x->wire_in_cap;
     if (x->local) (void)hipFree(x->local);
+    if (x->eager_out) (void)hipFree(x->eager_out);
+    if (x->eager_in) (void)hipFree(x->eager_in);
+    if (x->caps_dev) (void)hipFree(x->caps_dev);
+    delete[] x->eager_slot;
     if (x->hdr_dev) (void)hipFree(x->hdr_dev);
     if (x->sizes_dev) (void)hipFree(x->sizes_dev);
     if (x->sizes_host) (void)hipHostFree(x->sizes_host);
@@ -1706,6 +1762,8 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     x->stride = x->cap + kSlotHeaderWords;
     { const char *e = getenv("PQPS_EXCHANGE_COMPACT"); x->compact = !e || atoi(e) != 0; }
     { const char *e = getenv("PQPS_EXCHANGE_TIMEOUT_S"); x->timeout_s = e ? atof(e) : 30.0; if (x->timeout_s < 0) x->timeout_s = 0; }
+    { const char *e = getenv("PQPS_EXCHANGE_EAGER_IDS"); x->eager_want = e ? strtoull(e, nullptr, 10) : kEagerIdsDefault; }
+    x->eager_slot = new bool[ring]();
     int rc = load_rccl(rccl_library, &x->rccl);
     if (rc) { pqps_exchange_destroy(x); return rc; }
 #define X_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { pqps_exchange_destroy(x); \
@@ -1812,6 +1870,21 @@ int exchange_payload(pqps_exchange *x, uint32_t slot) {
         reported += hdr[r * kWireHeaderWords];
         total += held(r);
         if (r != x->rank && hdr[r * kWireHeaderWords + 3]) staged += (wire_bytes(hdr[r * kWireHeaderWords + 1], held(r)) + 15) & ~15ull;
+    }
+    x->select_queries++;
+    if (x->eager_ids) {                                          // what the next query gathers: every rank reads the same headers at the same point of its call sequence
+        bool fits = true;
+        for (uint32_t r = 0; r < x->world; r++) if (hdr[r * kWireHeaderWords] > x->eager_ids) fits = false;
+        x->eager_next = fits;
+        if (fits && x->eager_slot[slot]) {                       // the gathered blocks held the whole answer, and it is in place (eager_unpack_kernel)
+            for (uint32_t r = 0; r < x->world; r++)
+                if (r != x->rank) { x->wire_bytes_in += held(r) * 4; x->u32_bytes_in += held(r) * 4; }
+            x->eager_queries++;
+            x->totals_host[2 * slot] = total;
+            x->totals_host[2 * slot + 1] = reported;
+            x->state[slot] = kSlotDone;                          // (merge_done was recorded with the sizes: nothing of this query is left to enqueue)
+            return PQPS_OK;
+        }
     }
     int grow = PQPS_OK;
     if (total > x->merged_cap[slot]) {
@@ -1952,15 +2025,46 @@ int pqps_exchange_connect(pqps_exchange *x, const pqps_rccl_id *id) {
     // have to size their receives the same way
     x->caps[x->rank] = x->cap;
     if (x->world > 1) {
+        // (with it: the room for eager IDs every rank asks for -- the smallest wins, so ranks started with different settings still agree)
         uint64_t *mine = x->sizes_dev, *all = x->sizes_host;      // slot 0's buffers, not in use yet
-        HIP_TRY(hipMemcpyAsync(x->local, &x->cap, sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
-        nrc = x->rccl.AllGather(x->local, mine, 1, kRcclUint64, x->comm, x->stream);
+        const uint64_t hello[2] = {x->cap, x->eager_want};
+        HIP_TRY(hipMemcpyAsync(x->local, hello, sizeof hello, hipMemcpyHostToDevice, x->stream));
+        nrc = x->rccl.AllGather(x->local, mine, 2, kRcclUint64, x->comm, x->stream);
         if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
-        HIP_TRY(hipMemcpyAsync(all, mine, (size_t)x->world * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
-        HIP_TRY(hipMemsetAsync(x->local, 0, sizeof(uint64_t), x->stream));
-        const int rc = exchange_wait_stream(x, x->stream, "the capacities all-gather");
+        HIP_TRY(hipMemcpyAsync(all, mine, (size_t)x->world * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipMemsetAsync(x->local, 0, sizeof hello, x->stream));
+        int rc = exchange_wait_stream(x, x->stream, "the capacities all-gather");
         if (rc) return rc;
-        for (uint32_t r = 0; r < x->world; r++) x->caps[r] = all[r];
+        uint64_t eager = ~0ull;
+        for (uint32_t r = 0; r < x->world; r++) {
+            x->caps[r] = all[2 * r];
+            if (all[2 * r + 1] < eager) eager = all[2 * r + 1];
+            if (x->caps[r] < eager) eager = x->caps[r];           // (a block never holds more than the smallest slot does)
+        }
+        memset(all, 0, (size_t)x->world * 2 * sizeof(uint64_t));
+        const uint64_t most = ((uint64_t)1 << 20) / x->world;     // the gathered blocks of a query: 4 MB at most
+        if (eager > most) eager = most;
+        eager &= ~1ull;
+        x->eager_ids = eager >= 256 ? eager : 0;
+        if (x->eager_ids) {
+            x->eager_block = kWireHeaderWords * sizeof(uint64_t) + x->eager_ids * 4;
+            HIP_TRY(hipMalloc((void **)&x->eager_out, (size_t)x->ring * x->eager_block));
+            HIP_TRY(hipMalloc((void **)&x->eager_in, (size_t)x->ring * x->world * x->eager_block));
+            HIP_TRY(hipMalloc((void **)&x->caps_dev, (size_t)x->world * sizeof(uint64_t)));
+            HIP_TRY(hipMemcpyAsync(x->caps_dev, x->caps, (size_t)x->world * sizeof(uint64_t), hipMemcpyHostToDevice, x->stream));
+            HIP_TRY(hipMemsetAsync(x->eager_out, 0, (size_t)x->ring * x->eager_block, x->stream));
+            rc = exchange_wait_stream(x, x->stream, "setting up the eager blocks");
+            if (rc) return rc;
+            for (uint32_t i = 0; i < x->ring; i++) {              // the gathered list of a slot holds every rank's eager IDs without growing
+                if (x->merged_cap[i] >= x->world * x->eager_ids) continue;
+                (void)hipFree(x->merged[i]);
+                x->merged[i] = nullptr;
+                x->merged_cap[i] = 0;
+                HIP_TRY(hipMalloc((void **)&x->merged[i], (size_t)x->world * x->eager_ids * 4));
+                x->merged_cap[i] = x->world * x->eager_ids;
+            }
+            x->eager_next = true;
+        }
     }
     return PQPS_OK;
 }
@@ -2041,22 +2145,41 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
     // sizes: mpi:753.  They are needed on the host (send / recv counts): a 32-byte-per-rank all-gather -- reported count,
     // the shard's rows and first row (what a receiver needs to rebuild IDs from the compact form), the form the sender
     // chose -- then a copy into pinned memory behind it.  The pack kernel writes this rank's words (and the compact payload).
+    x->eager_slot[slot] = false;
     if (x->world > 1) {
         const uint64_t n_max = x->cap < n_rows ? x->cap : n_rows;
+        const bool eager = x->eager_ids && x->eager_next;
         uint64_t blocks = compact ? (n_max + 2047) / 2048 : 1;
+        if (eager && blocks < 8) blocks = 8;
         const uint64_t max_blocks = (uint64_t)x->ctx->compute_units * 8;
         if (blocks > max_blocks) blocks = max_blocks;
         if (blocks == 0) blocks = 1;
+        uint8_t *block_out = eager ? x->eager_out + (uint64_t)slot * x->eager_block : nullptr;
+        uint8_t *blocks_in = eager ? x->eager_in + (uint64_t)slot * x->world * x->eager_block : nullptr;
         hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, x->stream, local, x->cap, n_rows, id_base, compact ? 1 : 0,
-                           wire_min_ids(), hdr_dev, x->wire_out[slot]);
+                           wire_min_ids(), eager ? (uint64_t *)block_out : hdr_dev, x->wire_out[slot], eager ? x->eager_ids : (uint64_t)0,
+                           eager ? (uint32_t *)(block_out + kWireHeaderWords * sizeof(uint64_t)) : nullptr);
         HIP_TRY(hipGetLastError());
-        int nrc = x->rccl.AllGather(hdr_dev, sizes_dev, kWireHeaderWords, kRcclUint64, x->comm, x->stream);
-        if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+        int nrc;
+        if (eager) {
+            // one collective for the sizes AND, where every rank's list fits its block, the answer (eager_unpack_kernel)
+            nrc = x->rccl.AllGather(block_out, blocks_in, (size_t)(x->eager_block / sizeof(uint64_t)), kRcclUint64, x->comm, x->stream);
+            if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+            hipLaunchKernelGGL(eager_unpack_kernel, dim3(4, x->world), dim3(256), 0, x->stream, blocks_in, x->world, x->eager_block, x->eager_ids,
+                               x->caps_dev, x->merged[slot], sizes_dev);
+            HIP_TRY(hipGetLastError());
+            x->eager_slot[slot] = true;
+        } else {
+            nrc = x->rccl.AllGather(hdr_dev, sizes_dev, kWireHeaderWords, kRcclUint64, x->comm, x->stream);
+            if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+        }
         HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * kWireHeaderWords * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
     } else {
         HIP_TRY(hipMemcpyAsync(sizes_host, local, sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));    // (words 1 - 3 stay 0: nobody to tell)
     }
     HIP_TRY(hipEventRecord(x->sizes_done[slot], x->stream));
+    // (an eager query may be complete at this point of the stream; if it is not, its payload step records the event again)
+    if (x->eager_slot[slot]) HIP_TRY(hipEventRecord(x->merge_done[slot], x->stream));
     x->state[slot] = kSlotSizesInFlight;
     x->issued[slot] = ++x->calls;
     return PQPS_OK;
@@ -2150,7 +2273,7 @@ int pqps_wire_pack(pqps_ctx *ctx, const uint32_t *slot, uint64_t capacity, uint6
     const uint64_t max_blocks = (uint64_t)ctx->compute_units * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, slot, capacity, n_rows, id_base, enabled ? 1 : 0, wire_min_ids(), header_dev, (uint8_t *)wire);
+    hipLaunchKernelGGL(wire_pack_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, slot, capacity, n_rows, id_base, enabled ? 1 : 0, wire_min_ids(), header_dev, (uint8_t *)wire, (uint64_t)0, (uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return PQPS_OK;
 }
@@ -2170,6 +2293,14 @@ void pqps_exchange_wire_bytes(pqps_exchange *x, uint64_t out[2], int reset) {
     out[0] = x->wire_bytes_in;
     out[1] = x->u32_bytes_in;
     if (reset) x->wire_bytes_in = x->u32_bytes_in = 0;
+}
+
+void pqps_exchange_eager(pqps_exchange *x, uint64_t out[3], int reset) {
+    if (!x || !out) return;
+    out[0] = x->eager_queries;
+    out[1] = x->select_queries;
+    out[2] = x->eager_ids;
+    if (reset) x->eager_queries = x->select_queries = 0;
 }
 
 int pqps_exchange_sync(pqps_exchange *x) {

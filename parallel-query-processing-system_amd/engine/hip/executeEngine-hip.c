@@ -623,6 +623,17 @@ int hipEngineWireBytesHIP(struct engineS *engine, unsigned long long out[2], int
     return 0;
 }
 
+int hipEngineEagerQueriesHIP(struct engineS *engine, unsigned long long out[3], int reset) {
+    if (!engine || !engine->record_block || !out) return -1;
+    struct hipTable *t = engine->record_block;
+    uint64_t b[3] = { 0, 0, 0 };
+    if (t->xch) pqps_exchange_eager(t->xch, b, reset);
+    out[0] = b[0];
+    out[1] = b[1];
+    out[2] = b[2];
+    return 0;
+}
+
 int hipEngineLanes(struct engineS *engine) {
     if (!engine || !engine->record_block) return -1;
     return hipTableLaneCount(engine->record_block);

@@ -149,8 +149,8 @@ def test_library_exports_every_declared_symbol():
             "pqps_qstream_scan_slot", "pqps_qstream_wait", "pqps_copy_peer", "pqps_last_kernel",
             # round 4: ranks behind the engine API, the compact wire form, bounded waits, per-launch status, checks
             "initializeEngineSyntheticRankHIP", "hipEngineJoinRanksHIP", "hipEngineJoinPrepareHIP", "hipEngineJoinConnectHIP",
-            "hipEngineLeaveRanksHIP", "hipEngineRcclIdHIP", "hipEngineWireBytesHIP", "hipEngineLanes", "hipQueryChecksumHIP",
-            "pqps_wire_pack", "pqps_wire_expand", "pqps_wire_bytes", "pqps_wire_pays", "pqps_exchange_wire_bytes",
+            "hipEngineLeaveRanksHIP", "hipEngineRcclIdHIP", "hipEngineWireBytesHIP", "hipEngineEagerQueriesHIP", "hipEngineLanes", "hipQueryChecksumHIP",
+            "pqps_wire_pack", "pqps_wire_expand", "pqps_wire_bytes", "pqps_wire_pays", "pqps_exchange_wire_bytes", "pqps_exchange_eager",
             "pqps_ids_checksum", "pqps_qstream_reserve", "pqps_qstream_test_fail_slot", "pqps_ctx_set_option"} <= declared
     assert all(hasattr(lib, n) for n in ("hipTableLaneCount", "hipTableLocksCreate", "hipTableLocksDestroy", "hipTableAcquireLane"))
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]

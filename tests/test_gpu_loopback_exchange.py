@@ -95,6 +95,9 @@ WORKER = textwrap.dedent("""
                         got.append(["count", total, mine])
                     elif op == "y":
                         xch.sync()
+                eg = (C.c_uint64 * 3)()
+                L.pqps_exchange_eager(h, eg, 0)
+                got.append(["eager", int(eg[0]), int(eg[1]), int(eg[2])])
                 wb = (C.c_uint64 * 2)()
                 L.pqps_exchange_wire_bytes(h, wb, 0)
                 got.append(["wire", int(wb[0]), int(wb[1])])
@@ -140,9 +143,13 @@ CASES = {
 
 @pytest.mark.parametrize("world,compact,floor", [(2, True, "0"), (3, True, "0"), (2, False, "0"), (2, True, None)])
 def test_exchange_world_of_several_through_the_loopback(tmp_path, monkeypatch, world, compact, floor):
-    # floor None: the product's own rule -- only lists of 32 768 IDs and more travel compact (s1_sparse does not)
+    # floor None: the product's own rules -- only lists of 32 768 IDs and more travel compact (s1_sparse does not), and an answer of up to
+    # 16 384 IDs per rank arrives with the sizes (one collective); floor "0": compact lists of any size, no eager blocks
     if floor is None:
         monkeypatch.delenv("PQPS_WIRE_MIN_IDS")
+        monkeypatch.delenv("PQPS_EXCHANGE_EAGER_IDS", raising=False)
+    else:
+        monkeypatch.setenv("PQPS_EXCHANGE_EAGER_IDS", "0")
     assert LOOPBACK.exists(), "build it first: make -C tests/loopback (python __graft_entry__.py does)"
     cases = {k: (v[0], q.chain_to_jsonable(v[1]), v[2], v[3], v[4]) for k, v in CASES.items()}
     script = tmp_path / "worker.py"
@@ -161,6 +168,23 @@ def test_exchange_world_of_several_through_the_loopback(tmp_path, monkeypatch, w
             results = got[r][name]
             wire = results.pop()                                            # ["wire", bytes as they travelled, bytes as u32 IDs]
             assert wire[0] == "wire"
+            eager = results.pop()                                           # ["eager", SELECTs done in the one collective, SELECTs done, room]
+            assert eager[0] == "eager"
+            if floor is None:
+                caps, counts = [], []
+                for p in range(world):
+                    ps, pc = mg.shard_rows(rows, world, p)
+                    caps.append(((cap if cap else pc + 16) + 1) & ~1)
+                    counts.append(int(((want >= ps) & (want < ps + pc)).sum()))
+                room = min(16384, min(caps), (1 << 20) // world) & ~1
+                room = room if room >= 256 else 0                           # (one_row: the smallest slot holds 16 IDs -- not worth a block)
+                assert eager[3] == room, (name, eager, room)
+                if room and max(counts) <= room:
+                    assert eager[1] == eager[2] > 0, (name, r, eager)       # every answer of this case arrived with its sizes
+                else:
+                    assert eager[1] == 0 and eager[2] > 0, (name, r, eager)  # none did: they took the two steps
+            else:
+                assert eager[1] == 0 and eager[3] == 0, (name, eager)
             # the model: every finished SELECT brings in each peer's list -- compact where that is smaller
             selects = sum(1 for s in plan if s[0] == "s")
             in_wire = in_u32 = 0
@@ -279,9 +303,9 @@ STALL_WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("world,stall", [(2, "1:4"), (3, "0:4")])
+@pytest.mark.parametrize("world,stall", [(2, "1:4"), (3, "0:4"), (2, "0:2")])
 def test_a_stalled_payload_group_ends_in_abort_and_fallback(tmp_path, world, stall):
-    """One rank's payload group never finishes on the device.  Every rank's bounded wait runs out (PQPS_EXCHANGE_TIMEOUT_S),
+    """One rank's payload group (op 4 of the communicator; op 2: the sizes all-gather of the second query) never finishes on the device.  Every rank's bounded wait runs out (PQPS_EXCHANGE_TIMEOUT_S),
     the communicator is aborted, later calls fail at once, the exchange tears down, and all ranks finish on a fallback --
     the whole thing within seconds, no rank left behind."""
     assert LOOPBACK.exists()

@@ -512,6 +512,12 @@ def test_bench_engine_level_with_several_ranks_through_the_process_loopback(rank
     assert ("engine API" if level == "engine" else "shim-driven") in d["config"]["parallelism"]
     if "Q_A" in extra:
         assert "bytes on the wire" in d["config"]["parallelism"]               # the compact form's accounting made it into the record
+        assert " 0 of " in d["config"]["parallelism"]                          # 44 000 / 29 000 IDs per rank: the two-step path
+    elif "count" not in extra:
+        # S1 (the default workload): 67 IDs per rank -- every exchanged query finished in the sizes all-gather
+        import re
+        m = re.search(r"(\d+) of (\d+) exchanged queries finished in the one collective", d["config"]["parallelism"])
+        assert m and int(m.group(1)) == int(m.group(2)) > 0, d["config"]["parallelism"]
 
 
 def test_flags_mode(ctx):
