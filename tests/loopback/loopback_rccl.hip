@@ -32,7 +32,7 @@
 namespace {
 
 enum { kOk = 0, kUnhandledHip = 1, kSystemError = 2, kInternalError = 3, kInvalidArgument = 4, kInvalidUsage = 5 };
-constexpr int kMaxRanks = 16;
+constexpr int kMaxRanks = 32;
 
 struct P2P { bool send; int peer; const void *src; void *dst; size_t bytes; };
 
