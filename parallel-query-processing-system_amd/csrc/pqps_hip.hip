@@ -1671,6 +1671,7 @@ struct pqps_exchange {
     uint64_t *hdr_dev;               // [ring][4]        this rank's words of the sizes all-gather: reported count, rows, id_base, format
     uint64_t *sizes_dev;             // [ring][world][4] gathered headers
     uint64_t *sizes_host;            // [ring][world][4] ... on the host (pinned)
+    uint64_t *sizes_host_dev;        //                  ... as the device addresses it (the eager unpack kernel writes the headers there itself)
     uint8_t **wire_out;              // [ring]           this rank's payload in compact form (wire_pack_kernel), grown to the rows of a call
     uint64_t *wire_out_cap;
     uint8_t **wire_in;               // [ring]           the peers' compact payloads as received, grown to what a query needs
@@ -1783,6 +1784,7 @@ int pqps_exchange_prepare(pqps_ctx *ctx, const char *rccl_library, uint32_t worl
     X_TRY(hipMemsetAsync(x->totals, 0, (size_t)ring * 2 * sizeof(uint64_t), x->stream));
     X_TRY(hipStreamSynchronize(x->stream));
     memset(x->sizes_host, 0, (size_t)ring * world * kWireHeaderWords * sizeof(uint64_t));
+    X_TRY(hipHostGetDevicePointer((void **)&x->sizes_host_dev, x->sizes_host, 0));
     x->scan_done = new hipEvent_t[ring](); x->k1_done = new hipEvent_t[ring](); x->sizes_done = new hipEvent_t[ring]();
     x->merge_done = new hipEvent_t[ring]();
     x->child = new pqps_ctx *[kExchangeLanes](); x->state = new uint8_t[ring](); x->issued = new uint64_t[ring]();
@@ -2165,15 +2167,16 @@ int pqps_exchange_select(pqps_exchange *x, const pqps_column *cols, uint32_t n_c
             // one collective for the sizes AND, where every rank's list fits its block, the answer (eager_unpack_kernel)
             nrc = x->rccl.AllGather(block_out, blocks_in, (size_t)(x->eager_block / sizeof(uint64_t)), kRcclUint64, x->comm, x->stream);
             if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+            // (the headers go straight into the pinned host words: no copy launch behind the kernel)
             hipLaunchKernelGGL(eager_unpack_kernel, dim3(4, x->world), dim3(256), 0, x->stream, blocks_in, x->world, x->eager_block, x->eager_ids,
-                               x->caps_dev, x->merged[slot], sizes_dev);
+                               x->caps_dev, x->merged[slot], x->sizes_host_dev + (uint64_t)slot * x->world * kWireHeaderWords);
             HIP_TRY(hipGetLastError());
             x->eager_slot[slot] = true;
         } else {
             nrc = x->rccl.AllGather(hdr_dev, sizes_dev, kWireHeaderWords, kRcclUint64, x->comm, x->stream);
             if (nrc) return fail(PQPS_EHIP, "ncclAllGather: %s", x->rccl.GetErrorString(nrc));
+            HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * kWireHeaderWords * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
         }
-        HIP_TRY(hipMemcpyAsync(sizes_host, sizes_dev, (size_t)x->world * kWireHeaderWords * sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));
     } else {
         HIP_TRY(hipMemcpyAsync(sizes_host, local, sizeof(uint64_t), hipMemcpyDeviceToHost, x->stream));    // (words 1 - 3 stay 0: nobody to tell)
     }
