@@ -12,12 +12,14 @@
 //            widest predicate column is ONE fully coalesced global_load_dwordx4 per chunk and narrower
 //            ones dwordx2 / dword / ushort loads that are just as contiguous across the wave.  A leaf is
 //            the unsigned window test ((x - lo) <= span) ^ neg; the boolean tree is a 64-entry truth
-//            table (<= 6 leaves) or a jump table.  Output per step, skipped when the step has no match: a list of
-//            16-bit row numbers in the context's list area (store_list16), or -- few matches, 1-byte columns,
-//            gathers -- a 128-byte slot with a packed 10-bit list or 16 match bits per lane; per tile ONE store of its steps' COUNT WORDS
+//            table (<= 6 leaves) or a jump table.  Output per step, skipped when the step has no match: up to 104
+//            matches as 16-bit entries (row inside the step's group) in the step's slot (store_list), more as a list of
+//            16-bit row numbers in the context's list area (store_list16) or -- no list area, 1-byte columns,
+//            gathers -- as 16 match bits per lane (128 bytes); per tile ONE store of its steps' COUNT WORDS
 //            (epoch << 16 | log2(RPL) << 11 | matches) by wave 0 after the tile's barrier.  The first two
 //            tiles of a group also do SUM DUTY for a group / supergroup `sum_lag` groups back (a hint).
-//  expand    turns the match bits of a GROUP (64 steps = 64 K rows) into ascending row IDs.  It needs the
+//  expand    turns what the steps of a GROUP (64 steps = 64 K rows) left into ascending row IDs (entries and lists: a
+//            copy at the step's own output offset; bit masks: ranked).  It needs the
 //            group's count words (all tagged with this query's epoch => its match words are in memory)
 //            and the matches in front of it: supergroup sums (64 groups each) + the earlier group sums of
 //            its own supergroup -- tagged words published by the tiles' sum duty or, failing that, by the
@@ -46,6 +48,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kStepRows = 1024;             // rows per wave per step = 64 lanes x 16 rows
 constexpr int kGroupSteps = 64;             // steps per scan group (64 K rows)
 constexpr int kRplGeneric = 4;              // generic kernel: 4 consecutive rows per lane per chunk
+constexpr int kSlotWords = 64;              // 16-bit entries of a step's slot in each of the two list areas of the sparse steps (128 bytes)
 
 enum Mode { MODE_IDS = 0, MODE_COUNT = 1, MODE_FLAGS = 2 };
 
@@ -55,7 +58,10 @@ struct EvalArgs {
     uint64_t span[PQPS_MAX_LEAVES];
     uint64_t truth;
     uint64_t n_rows;                 // scan: rows; gather: caller's upper bound (range is on the device)
-    uint16_t *masks;                 // [steps][64] match bits of every lane
+    uint16_t *masks;                 // [steps][64] match bits of every lane (steps that left a bit mask)
+    uint16_t *slots;                 // [steps][64] 16-bit entries of the steps with few matches (store_list): entries 0 .. 63
+    uint16_t *slots_hi;              // [steps][64] ... entries 64 .. 127 (two dense arrays of 128-byte lines: one array of 256-byte slots
+                                     //            of which a few-percent answer fills the first half costs the scan 2 - 5 %)
     uint32_t *counts;                // [steps]     epoch << 16 | log2(RPL) << 11 | matches
     uint16_t *lists;                 // [steps][1024] row lists of the fuller steps (see store_list16), or nullptr: bit masks for those
     uint8_t *out_flags;              // MODE_FLAGS
@@ -78,7 +84,9 @@ struct EvalArgs {
     uint32_t sum_lag;                // groups between a group's scan tiles and the tile that sums it up (< lag)
     uint32_t grid_groups;            // gather: groups the grid was sized for (a wider range: the workgroups loop)
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
-    uint16_t list16_min[2];          // a step with MORE matches than this leaves a 16-bit row list ([1]: widest predicate column 1 byte wide)
+    // (32-bit fields: a 16-bit kernel argument picked by a run-time index is fetched with a VECTOR load, on the tile's path)
+    uint32_t list16_min, list16_min_u8;   // a step with MORE matches than this leaves a 16-bit row list (_u8: widest predicate column 1 byte wide)
+    uint32_t list_max, list_max_u8;       // a step with at most this many matches leaves them as 16-bit entries in its slot (<= kListIds)
     uint32_t tune;                   // A/B switches of tuning runs (PQPS_TUNE): bit 0 = no second look ahead of early expander waves
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -756,31 +764,29 @@ __device__ __forceinline__ void sum_duty_finish(CArgs &a, const SumDuty &d, uint
     }
 }
 
-// A step with at most kListIds matches leaves them as a LIST: their row numbers inside the step (0 .. 1023, 10 bits
-// each, packed) in ascending order, in the same 128 bytes a bit mask would take.  Turning bits into ranked row numbers
-// is the expensive part of the expansion (~70 vector instructions per step for a few-percent answer, and the
-// expanders behind the last tile have nothing to hide them under: 22 us of a 90 us Q_A at 100 M rows), whereas a
-// scan tile's vector units idle while it waits for memory.  What is left for the expander is a copy: list entry +
-// first row of the step -> ID.  Denser steps keep the bit mask (one 128-byte slot per step either way; which of the
-// two forms a slot holds follows from the step's count).
+// A step with at most a.list_max matches (host: kListIds) leaves them as a LIST in its slot: 16-bit row numbers inside the
+// step's GROUP (step-in-group << 10 | row-in-step), ascending, 2 bytes per match -- only the 8-byte words that hold
+// entries are stored.  Turning bits into ranked row numbers is the expensive part of the expansion, and the expanders
+// have nothing to hide it under, whereas a scan tile's vector units idle while it waits for memory.  What is left for
+// the expander is a copy with NO per-step decoding and no LDS: lane i loads entry i of the step straight from the slot
+// (one 2-byte load per lane), adds the group's first row and stores at the step's output offset (expand_direct).
+// (The first form packed 10 bits per row into 128 bytes: one or two LDS atomics per match in the tile, and in the expander a
+// slot fetch into LDS, two LDS reads, a 64-bit shift and ~100 instructions of per-step control -- the expanders were
+// bound by their instructions, 2.2 - 2.6 TB/s of slot + ID traffic at 1 G rows.)  Denser steps keep a 16-bit list in the
+// list area (store_list16) or the bit mask; which form a step took follows from its count word (step_form).
 //
 // Row order: bit p of lane l is row (p / RPL) * 64 * RPL + l * RPL + p % RPL, i.e. chunk by chunk (16 / RPL chunks),
 // inside a chunk lane by lane.  The per-lane counts of the <= 4 chunks travel through ONE wave scan as 8-bit fields
-// (no field exceeds 102), the chunks' bases come from the last lane's fields.
-constexpr uint32_t kListIds = 102;          // 1024 bits / 10
-// ... unless the widest predicate column is one byte wide (RPL = 16): a step is then 1 KB of input, the scan tile
-// has ~100 instruction slots per step to keep up with HBM and none to spare (a lone u8 column with lists: 47.5 -> 54.3 us).
-__device__ __forceinline__ uint32_t list_limit(uint32_t rpl_log2) { return rpl_log2 >= 4u ? 0u : kListIds; }
+// (no field exceeds 128), the chunks' bases come from the last lane's fields.
+constexpr uint32_t kListIds = 2 * kSlotWords; // entries of a step's two 128-byte slots
+// ... of which the host asks for 104 (a.list_max): an answer of 12 - 14 % (around 128 matches per step) would otherwise leave its
+// steps in both forms, and a copied step in the middle of ranked ones interrupts their run of staged IDs (`risk_level > 2`,
+// 138 per step: 947 us at 1 G rows with 128, 916 with 104 or with bit masks only; Q_B, 69 per step: 932 either way)
+constexpr uint32_t kListDefault = 104;
+enum { FORM_NONE = 0, FORM_DIRECT = 1, FORM_LIST16 = 2, FORM_MASK = 3 };
 
-__device__ __forceinline__ uint32_t list_entry(const uint32_t *slot32, uint32_t i) {
-    const uint32_t bit = 10u * i, w = bit >> 5, sft = bit & 31u;
-    const uint64_t two = (uint64_t)slot32[w] | ((uint64_t)slot32[w < 31u ? w + 1u : 31u] << 32);   // (word 31 never needs a second one)
-    return (uint32_t)(two >> sft) & 0x3FFu;
-}
-
-__device__ __forceinline__ void store_list(CArgs &a, uint32_t *stage32, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
+__device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t rl, uint32_t lane) {
     const uint32_t rpl = 1u << rl, chunks = 16u >> rl;              // rl = 2, 3, 4: 4, 2, 1 chunks
-    if (lane < 32) stage32[lane] = 0u;
     uint32_t per = 0;
 #pragma unroll
     for (uint32_t c = 0; c < 4; c++)
@@ -790,20 +796,19 @@ __device__ __forceinline__ void store_list(CArgs &a, uint32_t *stage32, uint64_t
     const uint32_t base = (tot << 8) + (tot << 16) + (tot << 24);   // field c: matches of the chunks before c
     uint32_t at = base + incl - per;                                // field c: list slot of this lane's first match in chunk c
     uint32_t m = mbits;
-    const uint32_t lane_rows = lane << rl;
+    const uint32_t lane_rows = (((uint32_t)step & (kGroupSteps - 1u)) << 10) + (lane << rl);
     while (m) {                                                     // set bits only: ascending rows inside a chunk
         const uint32_t p = (uint32_t)__builtin_ctz(m);
         m &= m - 1;
         const uint32_t c = p >> rl, sh8 = 8u * c;
-        const uint32_t bit = 10u * ((at >> sh8) & 0xFFu), w = bit >> 5, sft = bit & 31u;
+        stage[(at >> sh8) & 0xFFu] = (uint16_t)((c << (6u + rl)) + lane_rows + (p & (rpl - 1u)));
         at += 1u << sh8;
-        const uint32_t row = (c << (6u + rl)) + lane_rows + (p & (rpl - 1u));
-        // (entries of different lanes share words: LDS atomics)
-        __hip_atomic_fetch_or(stage32 + w, row << sft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (sft > 22u) __hip_atomic_fetch_or(stage32 + w + 1, row >> (32u - sft), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < 16) st_sc1((uint64_t *)(a.masks + step * 64) + lane, ((const uint64_t *)stage32)[lane]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the same wave wrote the stage)
+    // whole 128-byte lines (entries past the count: whatever the stage held): a partly written line is a read-modify-write
+    // on the memory side.  Lanes 0 .. 15: entries 0 .. 63, lanes 16 .. 31: the second line of a step with more than 64.
+    if (lane < (cnt > 64u ? 32u : 16u))
+        st_sc1((uint64_t *)((lane < 16u ? a.slots : a.slots_hi) + step * kSlotWords) + (lane & 15u), ((const uint64_t *)stage)[lane]);
 }
 
 // A step with more than a.list16_min matches (host: 8) leaves them as a list of another kind when the launch has a list
@@ -814,20 +819,18 @@ __device__ __forceinline__ void store_list(CArgs &a, uint32_t *stage32, uint64_t
 // scan tile's vector units idle while it waits for memory; it ranks its own matches (two wave scans for the chunks'
 // per-lane counts, one LDS store per match) and the expander is left with a copy: four list entries + first row of
 // the step -> four IDs per lane and store.
-// (`step_uses_list16` must agree between the tile that writes and the expander that reads: both see the count word.)
-__device__ __forceinline__ bool step_uses_list16(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
-#ifdef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
-    (void)a; (void)cnt; (void)rpl_log2;
-    return false;
-#else
-    return a.lists != nullptr && cnt > (uint32_t)a.list16_min[rpl_log2 >= 4u ? 1 : 0];
+// (`step_form` must agree between the tile that writes and the expander that reads: both see the count word.)
+__device__ __forceinline__ uint32_t step_form(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
+    if (cnt == 0u) return FORM_NONE;
+    if (cnt <= (rpl_log2 >= 4u ? a.list_max_u8 : a.list_max)) return FORM_DIRECT;
+#ifndef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
+    if (a.lists != nullptr && cnt > (rpl_log2 >= 4u ? a.list16_min_u8 : a.list16_min)) return FORM_LIST16;
 #endif
+    return FORM_MASK;
 }
-// the steps of a group that have a 128-byte slot to fetch (`cw` = a step's count word)
-__device__ __forceinline__ bool step_has_slot(CArgs &a, uint32_t cw) {
-    const uint32_t cnt = cw & kCountMask;
-    return cnt != 0u && !step_uses_list16(a, cnt, (cw >> kRplShift) & 7u);
-}
+__device__ __forceinline__ uint32_t word_form(CArgs &a, uint32_t cw) { return step_form(a, cw & kCountMask, (cw >> kRplShift) & 7u); }
+// the steps of a group that have a 128-byte bit mask to fetch (`cw` = a step's count word)
+__device__ __forceinline__ bool step_has_slot(CArgs &a, uint32_t cw) { return word_form(a, cw) == FORM_MASK; }
 
 template <int RL>
 __device__ __forceinline__ void store_list16(CArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t lane) {
@@ -880,13 +883,14 @@ __device__ __forceinline__ void store_list16(CArgs &a, uint16_t *stage, uint64_t
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
-    if (step_uses_list16(a, cnt, rpl_log2)) {
+    const uint32_t form = step_form(a, cnt, rpl_log2);              // uniform
+    if (form == FORM_DIRECT) store_list(a, &sh.mask[threadIdx.x >> 6][0][0], step, mbits, cnt, rpl_log2, lane);
+    else if (form == FORM_LIST16) {
         uint16_t *stage = (uint16_t *)sh.stage[threadIdx.x >> 6];                  // 2 KB per wave: 1024 entries
         if (rpl_log2 == 2u) store_list16<2>(a, stage, step, mbits, cnt, lane);      // uniform
         else if (rpl_log2 == 3u) store_list16<3>(a, stage, step, mbits, cnt, lane);
         else store_list16<4>(a, stage, step, mbits, cnt, lane);
-    } else if (cnt > list_limit(rpl_log2)) store_mask(a, step, mbits, lane);
-    else if (cnt) store_list(a, (uint32_t *)&sh.mask[threadIdx.x >> 6][0][0], step, mbits, rpl_log2, lane);
+    } else if (form == FORM_MASK) store_mask(a, step, mbits, lane);
     if (lane == 0) sh.tile_cnt[slot] = cnt | (rpl_log2 << kRplShift);
 }
 
@@ -901,6 +905,14 @@ __device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_
 //   many matches: 64 rows at a time -- their match bits are the words of 4 lanes, read into an SGPR pair with
 //                 v_readlane; rank inside the 64 = mbcnt, so the 64 lanes store to consecutive slots.
 // The IDs of consecutive steps are consecutive in the output, so the ring carries over from step to step.
+// Row IDs that leave in runs of whole store instructions -- the copies of expand_direct, the 64 staged IDs of ring_flush --
+// go out with streaming (`nt`) stores: nothing on the device reads them again, and as write-back lines an answer of a few
+// percent displaces what the scan and the hand-off keep in L2 (same-process A/B, the copies only: Q_A at 1 G rows 724 -> 697
+// us, Q_B 960 -> 921; at 100 M rows Q_B 98.0 -> 94.2; with ring_flush a lone u8 column 45.1 -> 42.9).  NOT the stores of
+// the dense paths (64 rows at a time, lists of the list area): their instructions fill lines in parts that only L2 puts
+// together -- streaming, `risk_level > 1` (43 %) at 1 G rows took 1482 us instead of 1267.
+#define st_id(p, v) __builtin_nontemporal_store((v), (p))      /* (a macro: the pointee's `aligned(4)` must reach the builtin) */
+
 struct OutRing {
     uint32_t head, pending;          // wave-uniform: ring position of the oldest staged ID, staged IDs
     uint64_t pos;                    // output slot of the oldest staged ID (= of the next ID when nothing is staged)
@@ -910,7 +922,7 @@ __device__ __forceinline__ void ring_flush(CArgs &a, uint32_t *ring, OutRing &r,
     // n <= 64 staged IDs leave in one store instruction
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the same wave wrote the ring
     const uint32_t v = ring[(r.head + lane) & (kStageRing - 1)];
-    if (lane < n && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = v;
+    if (lane < n && r.pos + lane < a.out_cap) st_id(a.out_ids + r.pos + lane, v);
     r.head = (r.head + n) & (kStageRing - 1);
     r.pending -= n;
     r.pos += n;
@@ -925,6 +937,14 @@ __device__ __forceinline__ void ring_reserve(uint32_t *ring, OutRing &r, uint32_
     const uint32_t v = ring[(r.head + lane) & (kStageRing - 1)];
     if (lane < r.pending) ring[lane] = v;                           // (one wave: its LDS reads and writes keep their order)
     r.head = 0;
+}
+
+// The next ID goes to output slot `want`: steps that were copied elsewhere (16-bit entries, lists) interrupt the run of
+// the steps around them -- what is staged leaves first.
+__device__ __forceinline__ void ring_seek(CArgs &a, uint32_t *ring, OutRing &r, uint32_t lane, uint64_t want) {
+    if (r.pos + r.pending == want) return;                          // uniform
+    if (r.pending) ring_flush(a, ring, r, lane, r.pending);         // (< 64 staged IDs between steps)
+    r.pos = want;
 }
 
 template <int RL>                                               // log2(RPL): 2, 3 or 4
@@ -1158,34 +1178,67 @@ __device__ __forceinline__ void expand_lists16(CArgs &a, uint64_t step0, uint32_
     }
 }
 
+// Steps whose matches were left as 16-bit entries in their slots (FORM_DIRECT): a copy without LDS and without
+// per-step decoding.  `rest` = those steps of group g (bit = step in group) still to do; the first NS of them are taken:
+// NS four-byte loads per lane go out before any is awaited (lane i: entries 2 i and 2 i + 1 of the step -- a slot's 128
+// entries are one load instruction), then per step two adds and one 8-byte store per lane at the step's own output
+// offset (4-byte aligned, which global memory accesses may be; lane l of `lim_v` / `off_v` holds, for step l of the
+// group, the entries that have a place in the caller's buffer and the output slot of the first, counted from `obase`).
+// `big`: the steps with more than 64 entries.  Returns the steps left.
+typedef __attribute__((address_space(1))) char global_char;
+template <bool GATHER, int NS>
+__device__ __forceinline__ uint64_t expand_direct(CArgs &a, uint64_t begin, uint64_t g, uint64_t rest, uint64_t big, uint32_t lim_v, uint32_t off_v,
+                                                  uint32_t *obase, uint32_t lane) {
+    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    // lanes 0 .. 31: entries 0 .. 63 (first line); lanes 32 .. 63: entries 64 .. 127 from the second line if the step has
+    // one (`big`), otherwise the first line once more (same 128 bytes: no second memory access)
+    const uint32_t *lo = (const uint32_t *)(a.slots + g * kGroupSteps * kSlotWords) + (lane & 31u);
+    const uint32_t *hi = lane < 32u ? lo : (const uint32_t *)(a.slots_hi + g * kGroupSteps * kSlotWords) + (lane & 31u);
+    uint32_t st[NS];
+    uint32_t v[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        // every lane loads (no step left: the group's first slot once more) -- no branch around a load, ONE wait for all
+        st[i] = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+        rest &= rest - 1;                                           // (0 stays 0)
+        const uint32_t sl = st[i] & 63u;
+        v[i] = ld_sc1((((big >> sl) & 1ull) ? hi : lo) + sl * (uint32_t)(kSlotWords / 2));
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+    const uint32_t gbase = (uint32_t)(g * kGroupSteps * kStepRows), e0 = 2u * lane;
+    const uint32_t add = GATHER ? a.id_base : gbase + a.id_base;
+    global_char *ob = (global_char *)obase;
+    uint32_t c0[GATHER ? NS : 1], c1[GATHER ? NS : 1];
+    if constexpr (GATHER) {                                         // the candidate numbers of the listed rows, all requested before the stores
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+            const uint32_t lim = st[i] < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lim_v, (int)(st[i] & 63u)) : 0u;
+            c0[i] = a.cand[begin + (e0 < lim ? gbase + (v[i] & 0xFFFFu) : 0u)];
+            c1[i] = a.cand[begin + (e0 + 1u < lim ? gbase + (v[i] >> 16) : 0u)];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        if (st[i] >= 64u) break;                                    // uniform
+        const uint32_t lim = (uint32_t)__builtin_amdgcn_readlane((int)lim_v, (int)st[i]);
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)off_v, (int)st[i]);
+        u32x2_a4 id;
+        id.x = (GATHER ? c0[GATHER ? i : 0] : (v[i] & 0xFFFFu)) + add;
+        id.y = (GATHER ? c1[GATHER ? i : 0] : (v[i] >> 16)) + add;
+        // (a group's IDs are at most 256 KB: byte offsets in 32 bits, scalar base + vector offset)
+        global_char *o = ob + ((off + e0) << 2);
+        if (e0 + 1u < lim) st_id((__attribute__((address_space(1))) u32x2_a4 *)o, id);
+        else if (e0 < lim) st_id((__attribute__((address_space(1))) uint32_t *)o, id.x);      // the last entry of an odd count
+    }
+    return rest;
+}
+
 template <bool GATHER>
 __device__ __forceinline__ void expand_step(CArgs &a, uint64_t begin, uint64_t step, const uint16_t *slot, uint32_t rpl_log2,
                                             uint32_t count, uint32_t lane, uint32_t *ring, OutRing &r) {
     if constexpr (!GATHER)
-        if (step_uses_list16(a, count, rpl_log2)) { expand_step_list16(a, step, count, lane, ring, r); return; }   // uniform
-    if (count <= list_limit(rpl_log2)) {
-#pragma unroll 1
-        for (uint32_t i0 = 0; i0 < count; i0 += 64) {               // uniform: one round, two for more than 64 entries
-            const uint32_t n = count - i0 < 64u ? count - i0 : 64u;
-            uint32_t id = 0;
-            if (lane < n) {
-                const uint32_t row = (uint32_t)(step * kStepRows) + list_entry((const uint32_t *)slot, i0 + lane);
-                id = row;
-                if constexpr (GATHER) id = a.cand[begin + row];     // (a listed row lies inside the probed range)
-                id += a.id_base;
-            }
-            if (r.pending == 0) {                                   // uniform: nothing staged -> straight to the output, one store
-                if (lane < n && r.pos + lane < a.out_cap) a.out_ids[r.pos + lane] = id;
-                r.pos += n;
-                continue;
-            }
-            ring_reserve(ring, r, lane, n);
-            if (lane < n) ring[r.head + r.pending + lane] = id;
-            r.pending += n;
-            while (r.pending >= 64) ring_flush(a, ring, r, lane, 64);
-        }
-        return;
-    }
+        if (step_form(a, count, rpl_log2) == FORM_LIST16) { expand_step_list16(a, step, count, lane, ring, r); return; }   // uniform
     const uint32_t word = step_row_word(slot[lane], rpl_log2, lane);
     if (count <= kDirectIds) {
         expand_step_sparse<GATHER>(a, begin, step, word, count, lane, ring, r);
@@ -1317,7 +1370,7 @@ __device__ __forceinline__ uint32_t leader_prefetch_with(CArgs &a, FusedShared &
     // from list16_min + 1 on -- those have no slot).  The packed order is taken exactly when expand_range's sparse branch
     // will run: at most 16 NON-EMPTY steps, whichever form they left.
     const uint64_t nonempty = __ballot(step_has_slot(a, c));
-    const uint64_t any_match = __ballot((c & kCountMask) != 0u);
+    const uint64_t any_match = __ballot(word_form(a, c) >= (uint32_t)FORM_LIST16);   // (steps with 16-bit entries in their slots are copied without LDS)
     const uint32_t *gm = (const uint32_t *)(a.masks + g * kGroupSteps * 64) + lane;
     if (wave_sum_u32(c & kCountMask) <= kSoloIds && __popcll(any_match) <= (int)(kGroupSteps / kWaves)) {
         uint32_t k = 0;
@@ -1365,9 +1418,22 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
     const uint64_t my_off = group_off + (incl - my_cnt);
     if (g + 1 == ex.groups && c0 == 0 && lane == 63) *a.out_count = group_off + incl;
     const uint64_t span = (c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
-    const uint64_t nonempty = __ballot(my_cnt != 0) & span;         // non-empty steps of the range (wave-uniform)
-    if (!nonempty) return;
-    const uint64_t slotted = __ballot(step_has_slot(a, cw)) & span; // ... those with a 128-byte slot to fetch (the others left a 16-bit list)
+    const uint64_t all_nonempty = __ballot(my_cnt != 0) & span;     // non-empty steps of the range (wave-uniform)
+    if (!all_nonempty) return;
+    // Steps that left 16-bit entries in their slots (what a sparse or a few-percent answer consists of): copied first, up to
+    // 16 steps to a round of loads, every step at its own output offset -- no LDS, no ring, no order among them.
+    const uint32_t form = word_form(a, cw);
+    const uint64_t direct = __ballot(form == FORM_DIRECT) & span;
+    if (direct) {                                                   // uniform
+        // entries that have a place in the caller's buffer (a result that does not fit is cut off, the count says so)
+        const uint64_t room = my_off < a.out_cap ? a.out_cap - my_off : 0ull;
+        const uint32_t lim_v = form != FORM_DIRECT ? 0u : (room < (uint64_t)my_cnt ? (uint32_t)room : my_cnt);
+        const uint64_t big = __ballot(my_cnt > (uint32_t)kSlotWords) & direct;
+        for (uint64_t rest = direct; rest;) rest = expand_direct<GATHER, GATHER ? 4 : 16>(a, ex.begin, g, rest, big, lim_v, incl - my_cnt, a.out_ids + group_off, lane);
+    }
+    const uint64_t nonempty = all_nonempty & ~direct;               // what is left: 16-bit lists in the list area, bit masks
+    if (!nonempty) { if (c0 == 0) PQPS_STAMP_GROUP(a, g, 6); return; }
+    const uint64_t slotted = __ballot(form == FORM_MASK) & span;    // ... those with a 128-byte bit mask to fetch
     const uint32_t rpl_log2 = ((uint32_t)__builtin_amdgcn_readlane((int)cw, (int)__builtin_ctzll(nonempty)) >> kRplShift) & 7u;   // one per query
     uint32_t *ring = sh.stage[park];
     OutRing r;
@@ -1399,6 +1465,7 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
             const uint32_t st = (uint32_t)__builtin_ctzll(rest);
             const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
             k = (uint32_t)__popcll(slotted & ((1ull << st) - 1ull));  // packed: slot k = the k-th step that has one
+            ring_seek(a, ring, r, lane, readlane_u64(my_off, (int)st));
             expand_step<GATHER>(a, ex.begin, g * kGroupSteps + st, sh.mask[park][have ? st - c0 : k], rpl_log2, cwi & kCountMask, lane, ring, r);
         }
         if (r.pending) ring_flush(a, ring, r, lane, r.pending);
@@ -1439,24 +1506,24 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
                 }
             }
         }
+#pragma unroll 1
         for (uint32_t bb = 0; bb < 4; bb++) {                       // blocks of 4 steps
             const uint32_t nb = (bits >> (4 * bb)) & 0xFu;
             if (!nb) continue;
             const uint32_t sidx0 = w0 + 4 * bb;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)quad, (int)sidx0);
             const uint32_t lb = (lists16 >> (4 * bb)) & 0xFu;
-            if (rpl_log2 == 4 && total <= kBlockIds && lb == 0u) {  // uniform
+            if (rpl_log2 == 4 && total <= kBlockIds && lb == 0u && ((uint32_t)(direct >> sidx0) & 0xFu) == 0u) {  // uniform
+                ring_seek(a, ring, r, lane, readlane_u64(my_off, (int)sidx0 + (int)__builtin_ctz(nb)));
                 expand_block16<GATHER>(a, ex.begin, g * kGroupSteps + sidx0, total, nb, &sh.mask[park][4 * bb], lane, ring, r);
                 continue;
             }
-            for (uint32_t i = 0; i < 4; i++) {
+#pragma unroll 1
+            for (uint32_t i = 0; i < 4; i++) {                      // (one copy of expand_step: the instruction cache is the scan tiles')
                 if (!((nb >> i) & 1u)) continue;
                 const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(sidx0 + i));
-                if ((lb >> i) & 1u) {                               // (done above; its IDs interrupt the run of the steps around it)
-                    if (r.pending) ring_flush(a, ring, r, lane, r.pending);
-                    r.pos += cwi & kCountMask;
-                    continue;
-                }
+                if ((lb >> i) & 1u) continue;                       // (done above; its IDs interrupt the run of the steps around it)
+                ring_seek(a, ring, r, lane, readlane_u64(my_off, (int)(sidx0 + i)));
                 expand_step<GATHER>(a, ex.begin, g * kGroupSteps + sidx0 + i, sh.mask[park][4 * bb + i], rpl_log2, cwi & kCountMask, lane, ring, r);
             }
         }
@@ -1614,6 +1681,15 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
                 const uint32_t st = (uint32_t)__builtin_ctzll(rest);
                 const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
                 const uint64_t step = g * kGroupSteps + st;
+                if (word_form(a, cwi) == FORM_DIRECT) {             // 16-bit entries in its slot: a copy (every lane: this step's limit and offset)
+                    if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+                    const uint32_t n = cwi & kCountMask;
+                    const uint64_t room = r.pos < a.out_cap ? a.out_cap - r.pos : 0ull;
+                    const uint32_t lim = room < (uint64_t)n ? (uint32_t)room : n;
+                    (void)expand_direct<GATHER, 1>(a, ex.begin, g, 1ull << st, n > (uint32_t)kSlotWords ? ~0ull : 0ull, lim, 0u, a.out_ids + r.pos, lane);
+                    r.pos += n;
+                    continue;
+                }
                 if (step_has_slot(a, cwi)) {                        // its 128 bytes into the wave's LDS slice, slot 0
                     const uint32_t v = lane < 32 ? ld_sc1((const uint32_t *)(a.masks + step * 64) + lane) : 0u;
                     if (lane < 32) ((uint32_t *)&sh.mask[park][0][0])[lane] = v;

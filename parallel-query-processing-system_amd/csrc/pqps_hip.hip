@@ -436,7 +436,8 @@ struct pqps_ctx {
     hipStream_t stream;
     // filter scratch, grown on demand
     uint64_t scratch_steps;     // capacity in steps of 1024 rows
-    uint16_t *masks;            // [steps][64] match words
+    uint16_t *masks;            // [steps][64] match words (steps that left a bit mask)
+    uint16_t *slots, *slots_hi; // [steps][kSlotWords] each: 16-bit entries 0 .. 63 / 64 .. 127 of the steps with at most kListIds matches
     uint32_t *counts;           // [steps] step counts; all zero between queries
     uint16_t *lists;            // [list_steps][1024] 16-bit row lists of the fuller steps (ID scans; allocated with the first one)
     uint64_t list_steps;
@@ -458,7 +459,7 @@ struct pqps_ctx {
     uint64_t *check_dev;        // [2] pqps_ids_checksum
     // per-context overrides of the launch parameters (pqps_ctx_set_option: A/B runs inside ONE process, where the physical
     // placement of the table is the same for every variant); -1 = the default
-    long opt_list16, opt_list16_min, opt_list16_min_u8, opt_expand_lag, opt_sum_lag, opt_tune;
+    long opt_list16, opt_list16_min, opt_list16_min_u8, opt_list_max, opt_list_max_u8, opt_expand_lag, opt_sum_lag, opt_tune;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     // optional per-launch timing (bench.py roofline)
@@ -478,10 +479,10 @@ hipStream_t pick_stream(pqps_ctx *ctx, void *stream) {
 }
 
 void free_scratch(pqps_ctx *ctx) {
-    void *all[] = {ctx->masks, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials, ctx->lists};
+    void *all[] = {ctx->masks, ctx->slots, ctx->slots_hi, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials, ctx->lists};
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->lists = nullptr; ctx->list_steps = 0;
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->scratch_steps = 0;
 }
@@ -508,6 +509,8 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     const uint64_t cap = steps + steps / 4 + 64;
     const uint64_t groups = (cap + kGroupSteps - 1) / kGroupSteps;
     HIP_TRY(hipMalloc((void **)&ctx->masks, cap * 64 * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->slots, cap * kSlotWords * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->slots_hi, cap * kSlotWords * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->gsum, groups * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&ctx->ssum, (groups / kSuperGroups + 1) * sizeof(uint64_t)));
@@ -842,6 +845,8 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     // kGatherGridGroups groups (4 M candidates); the kernel's workgroups loop if the range turns out wider.
     if (gather && mode == MODE_IDS && groups > kGatherGridGroups) groups = kGatherGridGroups;
     a.masks = ctx->masks;
+    a.slots = ctx->slots;
+    a.slots_hi = ctx->slots_hi;
     a.counts = ctx->counts;
     a.partials = ctx->partials;
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
@@ -896,8 +901,16 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         static const uint32_t from_u8 = [] { const char *e = tuning_env("PQPS_LIST16_MIN_U8"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; }();
         const uint32_t f0 = ctx->opt_list16_min >= 0 ? (uint32_t)ctx->opt_list16_min : from;
         const uint32_t f1 = ctx->opt_list16_min_u8 >= 0 ? (uint32_t)ctx->opt_list16_min_u8 : from_u8;
-        a.list16_min[0] = (uint16_t)(f0 < 1024u ? f0 : 1024u);
-        a.list16_min[1] = (uint16_t)(f1 < 1024u ? f1 : 1024u);
+        a.list16_min = f0 < 1024u ? f0 : 1024u;
+        a.list16_min_u8 = f1 < 1024u ? f1 : 1024u;
+        // 16-bit entries inside the step's slot up to this many matches (0: never); 1-byte columns: their tiles have no
+        // instruction slots to spare for ranking
+        // PQPS_LIST_MAX (tests): 0 = no step leaves entries in its slot (bit masks / the list area for every step), 128 = up to a full slot
+        static const long env_max = [] { const char *e = getenv("PQPS_LIST_MAX"); return e ? strtol(e, nullptr, 0) : -1l; }();
+        const uint32_t m0 = ctx->opt_list_max >= 0 ? (uint32_t)ctx->opt_list_max : (env_max >= 0 ? (uint32_t)env_max : kListDefault);
+        const uint32_t m1 = ctx->opt_list_max_u8 >= 0 ? (uint32_t)ctx->opt_list_max_u8 : 0u;
+        a.list_max = m0 < kListIds ? m0 : kListIds;
+        a.list_max_u8 = m1 < kListIds ? m1 : kListIds;
     }
     a.status = ctx->status_dev;
     a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
@@ -1010,13 +1023,13 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->scratch_steps = 0;
-    ctx->masks = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->lists = nullptr; ctx->list_steps = 0; ctx->lists_refused = false;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
     ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset.store(false);
     ctx->check_dev = nullptr;
-    ctx->opt_list16 = ctx->opt_list16_min = ctx->opt_list16_min_u8 = ctx->opt_expand_lag = ctx->opt_sum_lag = ctx->opt_tune = -1;
+    ctx->opt_list16 = ctx->opt_list16_min = ctx->opt_list16_min_u8 = ctx->opt_list_max = ctx->opt_list_max_u8 = ctx->opt_expand_lag = ctx->opt_sum_lag = ctx->opt_tune = -1;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
@@ -1137,6 +1150,7 @@ int pqps_ctx_set_option(pqps_ctx *ctx, const char *name, long value) {
     if (!ctx || !name) return fail(PQPS_EINVAL, "NULL argument");
     struct { const char *name; long *slot; } opts[] = {
         {"list16", &ctx->opt_list16}, {"list16_min", &ctx->opt_list16_min}, {"list16_min_u8", &ctx->opt_list16_min_u8},
+        {"list_max", &ctx->opt_list_max}, {"list_max_u8", &ctx->opt_list_max_u8},
         {"expand_lag", &ctx->opt_expand_lag}, {"sum_lag", &ctx->opt_sum_lag}, {"tune", &ctx->opt_tune},
     };
     for (auto &o : opts)

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6, help="rounds of (every build x `reps` launches)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--count", action="store_true")
+    ap.add_argument("--ctxs", type=int, default=1, help="contexts per build (each draws its own scratch placement: name#k; the line also gives the mean over them)")
     ap.add_argument("--copies", type=int, default=1, help="table copies the launches alternate between (2: nothing a launch reads is cache-resident)")
     args = ap.parse_args()
     pq, _ = bench.load_pkg()
@@ -60,14 +61,17 @@ def main():
         name, rest = spec.split("=", 1)
         path, *opts = rest.split("@")
         L = bind(ROOT / path, pq)
-        h = C.c_void_p()
-        if L.pqps_ctx_create(0, C.byref(h)) != 0:
-            sys.exit(f"{name}: {L.pqps_last_error().decode()}")
-        for o in opts:
-            k, v = o.split(":")
-            if L.pqps_ctx_set_option(h, k.encode(), int(v)) != 0:
+        for k_ctx in range(max(1, args.ctxs)):
+            h = C.c_void_p()
+            if L.pqps_ctx_create(0, C.byref(h)) != 0:
                 sys.exit(f"{name}: {L.pqps_last_error().decode()}")
-        builds.append((name, L, h))
+            for o in opts:
+                k, v = o.split(":")
+                if L.pqps_ctx_set_option(h, k.encode(), int(v)) != 0:
+                    sys.exit(f"{name}: {L.pqps_last_error().decode()}")
+            builds.append((name if args.ctxs <= 1 else f"{name}#{k_ctx}", L, h))
+    if args.ctxs > 1:                                                # interleave the contexts of the builds: a#0 b#0 a#1 b#1 ...
+        builds.sort(key=lambda b: int(b[0].rsplit("#", 1)[1]))
     print(f"rows={n:,}  builds: {[b[0] for b in builds]}  rounds={args.rounds} x reps={args.reps}", flush=True)
     for qname in names:
         chain, _sql = bench.QUERIES[qname]
@@ -106,6 +110,11 @@ def main():
                 med = statistics.median(times[name])
                 line += f"  {name} {med:7.1f} us [{min(times[name]):.1f}..{max(times[name]):.1f}] {byts / (med * 1e-6) / 8e12:.3f}"
             print(line, flush=True)
+            if args.ctxs > 1:
+                means = {}
+                for name, _, _ in builds:
+                    means.setdefault(name.rsplit("#", 1)[0], []).append(statistics.median(times[name]))
+                print("    mean over contexts: " + "  ".join(f"{k} {statistics.mean(v):7.1f} us {byts / (statistics.mean(v) * 1e-6) / 8e12:.3f}" for k, v in means.items()), flush=True)
 
 
 if __name__ == "__main__":

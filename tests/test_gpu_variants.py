@@ -7,6 +7,7 @@ small sizes through the shim's switches -- each in its own process, because the 
   * the recovery pass: every expander gives up at its first look (spin limit 0), no tile does sum duty -- the
     last expander publishes every sum and expands every group on its own
   * bit masks for the fuller steps (what a context without a list area falls back to)
+  * the three forms a step's matches are left in (entries in the slot up to 0 / 64 / 128 matches), under each of the above
   * a dense answer at > 600 M rows (default placement among the tiles; row lists, ranked bit masks and the 64-row
     expansion path): head and tail of the ID list bit-exact against the host twin, the middle by count and order
 """
@@ -52,8 +53,22 @@ def test_recovery_pass_expands_everything_on_its_own():
     run_driver(dict(env, PQPS_EXPAND_LAG="100000"), "sizes", "300001", "5000001")      # ... and when all expanders trail the tiles
 
 
+@pytest.mark.parametrize("list_max", ["0", "64", "128"])
+def test_steps_with_and_without_entries_in_their_slots(list_max):
+    """A step with at most `list_max` matches (default 104) leaves them as 16-bit entries in its slot (two 128-byte lines
+    from 65 entries on) and the expanders copy them; 0 = every step as a bit mask or a 16-bit list, 128 = up to a full
+    slot.  Every shape, the sizes, expanders among the tiles, the recovery pass (which copies step by step), and no
+    list area (entries or bit masks only)."""
+    env = {"PQPS_LIST_MAX": list_max}
+    run_driver(env, "shapes", "70001")
+    run_driver(env, "sizes", "1", "4097", "300001", str((1 << 21) + 17))
+    run_driver(dict(env, PQPS_EXPAND_LAG="5", PQPS_SUM_LAG="2"), "sizes", "65537", "300001", "9000001")
+    run_driver(dict(env, PQPS_EXPAND_SPIN_LIMIT="0", PQPS_SUM_LAG="2000000000", PQPS_EXPAND_LAG="0"), "sizes", "65537", "300001")
+    run_driver(dict(env, PQPS_LIST16="0"), "sizes", "4097", "300001", str((1 << 21) + 17))
+
+
 def test_fuller_steps_as_bit_masks_when_there_is_no_list_area():
-    """Steps with more than 102 matches leave 16-bit row lists in the context's list area (2 bytes per table row); a
+    """Steps with more than 104 matches leave 16-bit row lists in the context's list area (2 bytes per table row); a
     context that cannot get one (or PQPS_LIST16=0) keeps the bit masks and the ranking expansion for them."""
     run_driver({"PQPS_LIST16": "0"}, "shapes", "70001")
     run_driver({"PQPS_LIST16": "0"}, "sizes", "4097", "300001", str((1 << 21) + 17))
