@@ -2136,7 +2136,7 @@ struct RawStep {
     asm volatile("" :: "s"((a).n_rows), "s"((a).col[0]), "s"((a).col[1]), "s"((a).col[2]), "s"(gridDim.x),  \
                  "s"((a).masks), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask), "s"((a).lag), "s"((a).sum_lag), "s"((a).counts),     \
                  "s"((uint32_t)(a).leaf_begin[0]), "s"((uint32_t)(a).leaf_begin[1]), "s"((uint32_t)(a).leaf_begin[2]), \
-                 "s"((uint32_t)(a).leaf_begin[3]))
+                 "s"((uint32_t)(a).leaf_begin[3]), "s"((a).lists), "s"((a).list_max), "s"((a).list_max_u8), "s"((a).list16_min), "s"((a).list16_min_u8))
 
 // General tree of <= 6 leaves (row-mask path).
 template <int MODE, int W0, int W1, int W2, bool NT>
