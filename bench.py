@@ -1036,12 +1036,17 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
     # ---- configs[2]: index range-probe SELECT (sorted-permutation index = B+-tree leaf order) --------
     # bytes per SURVEY 8(d): slice_len * (4 [perm] + sum of gathered predicate column widths) + 4 * matches
     have = set(table.ptr)
-    specs = [("command_id", 0, "command_id >= n-1e6", [("command_id", ">=", str(start + count - 1_000_000))], start + count - 1_000_000, 2**64 - 1),
-             ("user_id", 1, "user_id = 1001", [("user_id", "=", "1001")], 1001, 1001),
-             ("risk_level", 1, "risk_level = 5", [("risk_level", "=", "5")], 5, 5)]
+    # (key in the record, indexed column, key kind, label, WHERE, probe window); the first four are the probed comparison itself (the
+    # probe's rows are copied), the last two carry a second condition (the gather filter evaluates the WHERE on the probe's rows)
+    specs = [("index_command_id", "command_id", 0, "command_id >= n-1e6", [("command_id", ">=", str(start + count - 1_000_000))], start + count - 1_000_000, 2**64 - 1),
+             ("index_user_id", "user_id", 1, "user_id = 1001", [("user_id", "=", "1001")], 1001, 1001),
+             ("index_risk_level", "risk_level", 1, "risk_level = 5", [("risk_level", "=", "5")], 5, 5),
+             ("index_risk_level_gt3", "risk_level", 1, "risk_level > 3 (the reference's Sample 3)", [("risk_level", ">", "3")], 4, 2**31 - 1),
+             ("index_user_id_and_sudo", "user_id", 1, "user_id = 1001 AND sudo_used = TRUE", [("user_id", "=", "1001"), "AND", ("sudo_used", "=", "TRUE")], 1001, 1001),
+             ("index_risk_level_gt3_and_sudo", "risk_level", 1, "sudo_used = TRUE AND risk_level > 3", [("sudo_used", "=", "TRUE"), "AND", ("risk_level", ">", "3")], 4, 2**31 - 1)]
     rng = torch.zeros(4, dtype=torch.int64, device=device)
-    for col, kind, label, chain, lo, hi in specs:
-        if col not in have:
+    for key, col, kind, label, chain, lo, hi in specs:
+        if not {leaf[0] for leaf in _leaves(chain)} <= have:
             continue
         w = table.width[col]
         perm = torch.empty(count, dtype=torch.int32, device=device)
@@ -1056,9 +1061,10 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
 
         def probe():
             cnt.zero_()
-            pq.check(L.pqps_index_probe(ctx.h, keys.data_ptr(), w, kind, count, lo & (2**64 - 1), hi & (2**64 - 1), rng.data_ptr(), sptr), "probe")
-            pq.check(L.pqps_filter_gather(ctx.h, cols, nc, perm.data_ptr(), rng.data_ptr(), count, start, C.byref(pred),
-                                          ids.data_ptr(), count, cnt.data_ptr(), sptr), "gather")
+            # one call per probe, as the engine issues it (engine/hip/executeEngine-hip.c): the probe, then its rows that pass the WHERE
+            # appended -- copied when the WHERE is the probed comparison itself, evaluated by the gather filter otherwise
+            pq.check(L.pqps_index_select(ctx.h, cols, nc, carr, perm.data_ptr(), keys.data_ptr(), kind, count, lo & (2**64 - 1), hi & (2**64 - 1),
+                                         start, C.byref(pred), rng.data_ptr(), ids.data_ptr(), count, cnt.data_ptr(), sptr), "index select")
         for _ in range(3):
             probe()
         torch.cuda.synchronize()
@@ -1072,9 +1078,9 @@ def extras_leg(pq, L, ctx, tables, count, start, sptr, torch, device, names, log
         slice_len = int(rng[1].item() - rng[0].item())
         matches = int(cnt[0].item())
         byts = slice_len * (4 + bpr) + 4 * matches
-        out[f"index_{col}"] = {"query": label, "index_build_ms": build_ms, "ms_per_query": ms, "slice_len": slice_len,
-                               "matches": matches, "GBps": byts / (ms * 1e-3) / 1e9,
-                               "rows_per_s_table": count / (ms * 1e-3)}
+        out[key] = {"query": label, "index_build_ms": build_ms, "ms_per_query": ms, "slice_len": slice_len,
+                    "matches": matches, "GBps": byts / (ms * 1e-3) / 1e9, "rows_per_s_table": count / (ms * 1e-3),
+                    "kernel": pq.lib().pqps_last_kernel().decode()}
         log(f"index {label}: build {build_ms:.1f} ms, probe+filter {ms * 1e3:.0f} us, slice {slice_len:,}, {matches:,} matches")
         del perm, keys
     # ---- projection on the device: the selected columns of the result rows, gathered by ID ----

@@ -23,6 +23,7 @@
  *                       -- as a permutation sorted (key asc, row desc), the
  *                       leaf order of engine/bplus.c:282-314,471-490.
  *   pqps_index_probe    findLeaf + the leaf walk of findRange (bplus.c:282-358).
+ *   pqps_index_select   one probe of executeQuerySelectSerial, whole (executeEngine-serial.c:358-448).
  *   pqps_partition      the block partition of engine/mpi/executeEngine-mpi.c:703-715.
  *   pqps_exchange_*     the per-query exchange of the MPI engine (executeEngine-mpi.c:717-768:
  *                       local scan of the rank's rows, MPI_Allgather of the sizes + MPI_Allgatherv of
@@ -198,6 +199,17 @@ int pqps_index_build(pqps_ctx *ctx, const pqps_column *col, uint64_t n_rows, int
 int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int key_kind,
                      uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
                      uint64_t *range, void *stream);
+
+/* One index probe of a query, whole: pqps_index_probe into `range`, then the probe's rows that satisfy `pred` appended
+ * as pqps_filter_gather does (executeEngine-serial.c:358-448: findRange, then the complete WHERE on every row found).
+ * `index_column` = the column the index (perm / sorted_keys) was built on.  When `pred` is nothing but the probed
+ * comparison itself -- ONE leaf on the indexed column whose window is [key_lo, key_hi], accepted when it holds (the
+ * reference's `risk_level > 3` with an index on risk_level) -- every row found passes, and the rows are copied in
+ * index order instead of evaluated (PQPS_INDEX_COPY=0, tests: always evaluate; same result). */
+int pqps_index_select(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, const pqps_column *index_column,
+                      const uint32_t *perm, const void *sorted_keys, int key_kind, uint64_t n_rows,
+                      uint64_t key_lo, uint64_t key_hi, uint32_t id_base, const pqps_predicate *pred,
+                      uint64_t *range, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *stream);
 
 /* DELETE on the device (engine/serial/executeEngine-serial.c:646-680 removes the matching rows and
  * keeps the survivors in order): `delete_flags` is what pqps_filter_flags produced (1 = row goes).

@@ -287,6 +287,7 @@ def lib():
     L.pqps_filter_gather.argtypes = [vp, C.POINTER(Column), u32, vp, vp, u64, u32, C.POINTER(Predicate), vp, u64, vp, vp]
     L.pqps_index_build.argtypes = [vp, C.POINTER(Column), u64, C.c_int, vp, vp, vp]
     L.pqps_index_probe.argtypes = [vp, vp, u32, C.c_int, u64, u64, u64, vp, vp]
+    L.pqps_index_select.argtypes = [vp, C.POINTER(Column), u32, C.POINTER(Column), vp, vp, C.c_int, u64, u64, u64, u32, C.POINTER(Predicate), vp, vp, u64, vp, vp]
     L.pqps_partition.argtypes = [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
     L.pqps_partition.restype = None
     L.pqps_synth_user_tables.argtypes = [u64, vp, vp]

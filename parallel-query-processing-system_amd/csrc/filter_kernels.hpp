@@ -504,46 +504,45 @@ __device__ __forceinline__ uint32_t eval_step_full(CArgs &a, uint64_t step_row0,
     return combine_leaves<R>(a, idx);
 }
 
-// Guarded path (last partial step, gather mode): one chunk (4 rows per lane) at a time
-// with element loads.  `pos` counts rows of the scan / positions of the candidate list.
-template <bool GATHER>
-__device__ __forceinline__ uint32_t eval_step_guarded(CArgs &a, uint64_t step_row0, uint64_t n_rows,
-                                                      uint64_t begin, uint32_t lane) {
-    uint32_t mbits = 0;
-#pragma unroll 1
-    for (int u = 0; u < 4; u++) {
-        const uint64_t r0 = step_row0 + (uint64_t)u * 256 + lane * kRplGeneric;
-        uint64_t row[4];
-        uint32_t idx[4];
+// Gather (index mode), all 1024 positions of a step at once: the 16 candidate numbers of a lane in ONE round of loads, then
+// one round per predicate column (16 element loads each) -- 1 + n_cols memory latencies per step.  The first form (a chunk of
+// 4 positions per lane at a time) took 2 per chunk = 8 for the one-column predicate of an index query, most of the 22 us such a launch lasts (its
+// 35 k candidates are 34 steps: nothing but latency).  The gather kernel may use 128 registers (two workgroups per CU).
+__device__ __forceinline__ uint32_t eval_step_gather(CArgs &a, uint64_t step_row0, uint64_t n_rows, uint64_t begin, uint32_t lane) {
+    constexpr int R = 16;
+    uint32_t row[R], idx[R], live = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            idx[j] = 0;
-            row[j] = ~0ull;
-            if (r0 + j < n_rows) row[j] = GATHER ? (uint64_t)a.cand[begin + r0 + j] : r0 + j;
-        }
-        for (uint32_t c = 0; c < a.n_cols; c++) {               // uniform
-            const char *base = (const char *)a.col[c];
-            const int wl = a.width_log2[c];
-            const uint32_t kb = a.leaf_begin[c], ke = a.leaf_begin[c + 1];
-            if (wl == 3) {
-                uint64_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = row[j] != ~0ull ? load_one(base, 3, row[j]) : 0;
-                apply_leaves<uint64_t, 4>(a, kb, ke, v, idx);
-            } else {
-                uint32_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = row[j] != ~0ull ? (uint32_t)load_one(base, wl, row[j]) : 0u;
-                apply_leaves<uint32_t, 4>(a, kb, ke, v, idx);
-            }
-        }
-        uint32_t m4 = combine_leaves<4>(a, idx);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (row[j] == ~0ull) m4 &= ~(1u << j);              // rows past the end never match
-        mbits |= m4 << (u * 4);
+    for (int p = 0; p < R; p++) {                                    // bit p <-> position (p / 4) * 256 + lane * 4 + p % 4 of the step
+        const uint64_t r = step_row0 + (uint64_t)(p / 4) * 256 + lane * kRplGeneric + (p % 4);
+        idx[p] = 0;
+        if (r < n_rows) live |= 1u << p;
+        row[p] = a.cand[begin + (r < n_rows ? r : 0)];              // (every lane loads: the range's first candidate is always there)
     }
-    return mbits;
+    for (uint32_t c = 0; c < a.n_cols; c++) {                       // uniform
+        const char *base = (const char *)a.col[c];
+        const int wl = a.width_log2[c];
+        const uint32_t kb = a.leaf_begin[c], ke = a.leaf_begin[c + 1];
+        if (wl == 3) {
+            uint64_t v[R];
+#pragma unroll
+            for (int p = 0; p < R; p++) v[p] = ((const uint64_t *)base)[row[p]];
+            apply_leaves<uint64_t, R>(a, kb, ke, v, idx);
+        } else {
+            uint32_t v[R];
+            if (wl == 2) {
+#pragma unroll
+                for (int p = 0; p < R; p++) v[p] = ((const uint32_t *)base)[row[p]];
+            } else if (wl == 1) {
+#pragma unroll
+                for (int p = 0; p < R; p++) v[p] = ((const uint16_t *)base)[row[p]];
+            } else {
+#pragma unroll
+                for (int p = 0; p < R; p++) v[p] = ((const uint8_t *)base)[row[p]];
+            }
+            apply_leaves<uint32_t, R>(a, kb, ke, v, idx);
+        }
+    }
+    return combine_leaves<R>(a, idx) & live;                        // positions past the range never match
 }
 
 // ---- ID output: tiles, groups, and the hand-off between scan and expand workgroups ------------------
@@ -1830,7 +1829,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
             if (step < ex.steps) {
                 const uint64_t step_row0 = step * kStepRows;
                 uint32_t mbits;
-                if (GATHER) mbits = eval_step_guarded<true>(a, step_row0, ex.n_rows, ex.begin, lane);
+                if (GATHER) mbits = eval_step_gather(a, step_row0, ex.n_rows, ex.begin, lane);
                 else {
                     mbits = eval_step_full<NT>(a, step_row0, lane);
                     if (step_row0 + kStepRows > ex.n_rows) mbits &= rows_below<kRplGeneric>(step_row0, ex.n_rows, lane);   // the partial last step

@@ -43,7 +43,7 @@ __device__ __forceinline__ bool key_less(K a, K b) { return a < b; }
 // remaining interval, so 100 M keys take 5-6 dependent loads instead of 27 (both bounds at once).
 //   range[0] = first position with key >= lo, range[1] = first position with key > hi
 template <typename K>
-__global__ __launch_bounds__(64) void probe_kernel(const K *keys, uint64_t n, K lo, K hi, uint64_t *range) {
+__global__ __launch_bounds__(64) void probe_kernel(const K *keys, uint64_t n, K lo, K hi, uint64_t *range, uint64_t *out_count, uint64_t *claim) {
     const uint64_t lane = threadIdx.x;
     uint64_t l0 = 0, r0 = n, l1 = 0, r1 = n;                   // invariant: answer in [l, r]
     while (l0 < r0 || l1 < r1) {                               // uniform
@@ -66,6 +66,33 @@ __global__ __launch_bounds__(64) void probe_kernel(const K *keys, uint64_t n, K 
     if (lane == 0) {
         range[0] = l0;
         range[1] = l1 < l0 ? l0 : l1;
+        if (claim) {                                               // pqps_index_select's copy: the probe's rows go to out[base ...), all of them
+            const uint64_t n = l1 > l0 ? l1 - l0 : 0, base = *out_count;
+            claim[0] = base;
+            *out_count = base + n;
+        }
+    }
+}
+
+// The rows of a probed range, appended: out[base + i] = perm[begin + i] + id_base (what the gather filter leaves when every
+// candidate passes).  Grid-stride: the range is known on the device only.
+__global__ __launch_bounds__(256) void append_range_kernel(const uint32_t *perm, const uint64_t *range, const uint64_t *claim, uint32_t id_base,
+                                                           uint32_t *out_ids, uint64_t out_cap) {
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));     // (the range begins anywhere: 4-byte aligned accesses)
+    const uint64_t begin = range[0], base = claim[0];
+    uint64_t n = range[1] > begin ? range[1] - begin : 0;
+    if (base >= out_cap) return;
+    if (n > out_cap - base) n = out_cap - base;                  // a result that does not fit is cut off (the count says what there was)
+    const uint32_t *src = perm + begin;
+    uint32_t *dst = out_ids + base;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (uint64_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            u32x4_a4 v = *(const u32x4_a4 *)(src + i);
+            v += id_base;
+            __builtin_nontemporal_store(v, (u32x4_a4 *)(dst + i));
+        } else {
+            for (uint64_t j = i; j < n; j++) dst[j] = src[j] + id_base;
+        }
     }
 }
 
@@ -1348,30 +1375,88 @@ int pqps_index_build(pqps_ctx *ctx, const pqps_column *col, uint64_t n_rows, int
     }
 }
 
-int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int key_kind,
-                     uint64_t n_rows, uint64_t key_lo, uint64_t key_hi, uint64_t *range, void *stream) {
-    if (!ctx || !range || (!sorted_keys && n_rows)) return fail(PQPS_EINVAL, "NULL argument");
-    hipStream_t s = pick_stream(ctx, stream);
+}  // extern "C"
+
+namespace {
+
+int launch_probe(const void *sorted_keys, uint32_t width, int key_kind, uint64_t n_rows, uint64_t key_lo, uint64_t key_hi,
+                 uint64_t *range, uint64_t *out_count, uint64_t *claim, hipStream_t s) {
     if (key_kind == 1) {
         if (width != 4) return fail(PQPS_EINVAL, "signed keys must be 4 bytes wide");
         hipLaunchKernelGGL((probe_kernel<int32_t>), dim3(1), dim3(64), 0, s, (const int32_t *)sorted_keys, n_rows,
-                           (int32_t)(uint32_t)key_lo, (int32_t)(uint32_t)key_hi, range);
+                           (int32_t)(uint32_t)key_lo, (int32_t)(uint32_t)key_hi, range, out_count, claim);
     } else if (width == 1) {
         hipLaunchKernelGGL((probe_kernel<uint8_t>), dim3(1), dim3(64), 0, s, (const uint8_t *)sorted_keys, n_rows,
-                           (uint8_t)key_lo, (uint8_t)key_hi, range);
+                           (uint8_t)key_lo, (uint8_t)key_hi, range, out_count, claim);
     } else if (width == 2) {
         hipLaunchKernelGGL((probe_kernel<uint16_t>), dim3(1), dim3(64), 0, s, (const uint16_t *)sorted_keys, n_rows,
-                           (uint16_t)key_lo, (uint16_t)key_hi, range);
+                           (uint16_t)key_lo, (uint16_t)key_hi, range, out_count, claim);
     } else if (width == 4) {
         hipLaunchKernelGGL((probe_kernel<uint32_t>), dim3(1), dim3(64), 0, s, (const uint32_t *)sorted_keys, n_rows,
-                           (uint32_t)key_lo, (uint32_t)key_hi, range);
+                           (uint32_t)key_lo, (uint32_t)key_hi, range, out_count, claim);
     } else if (width == 8) {
         hipLaunchKernelGGL((probe_kernel<uint64_t>), dim3(1), dim3(64), 0, s, (const uint64_t *)sorted_keys, n_rows,
-                           key_lo, key_hi, range);
+                           key_lo, key_hi, range, out_count, claim);
     } else {
         return fail(PQPS_EINVAL, "width %u not in {1,2,4,8}", width);
     }
     HIP_TRY(hipGetLastError());
+    return PQPS_OK;
+}
+
+// Is `pred` nothing but the probed comparison -- ONE leaf on the indexed column whose window is the probe's, accepted
+// when it holds?  Then every row the probe finds passes: key in [lo, hi] in the key's order <=> (key - lo) <= hi - lo in
+// w-bit arithmetic (two's complement for the signed keys), which is the leaf's own test.
+bool probe_implies_predicate(const pqps_column *cols, uint32_t n_cols, const pqps_column *index_column, int key_kind,
+                             uint64_t key_lo, uint64_t key_hi, const pqps_predicate *pred) {
+    static const bool enabled = [] { const char *e = getenv("PQPS_INDEX_COPY"); return !e || atoi(e) != 0; }();   // 0 (tests): always evaluate
+    if (!enabled || !pred || pred->n_leaves != 1) return false;
+    const pqps_leaf &lf = pred->leaf[0];
+    if (lf.column >= n_cols || cols[lf.column].data != index_column->data || cols[lf.column].width != index_column->width) return false;
+    const uint32_t w = index_column->width;
+    const uint64_t mask = w >= 8 ? ~0ull : ((1ull << (8 * w)) - 1ull);
+    if (key_kind == 1) { if ((int32_t)(uint32_t)key_lo > (int32_t)(uint32_t)key_hi) return false; }
+    else if ((key_lo & mask) > (key_hi & mask)) return false;      // an empty window: left to the filter
+    if (((lf.lo ^ key_lo) & mask) != 0 || ((lf.span ^ (key_hi - key_lo)) & mask) != 0) return false;
+    return ((pred->truth >> (1u ^ (lf.negate & 1u))) & 1ull) != 0;     // candidates: raw window hit = 1
+}
+
+}  // namespace
+
+extern "C" {
+
+int pqps_index_probe(pqps_ctx *ctx, const void *sorted_keys, uint32_t width, int key_kind,
+                     uint64_t n_rows, uint64_t key_lo, uint64_t key_hi, uint64_t *range, void *stream) {
+    if (!ctx || !range || (!sorted_keys && n_rows)) return fail(PQPS_EINVAL, "NULL argument");
+    return launch_probe(sorted_keys, width, key_kind, n_rows, key_lo, key_hi, range, nullptr, nullptr, pick_stream(ctx, stream));
+}
+
+int pqps_index_select(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, const pqps_column *index_column,
+                      const uint32_t *perm, const void *sorted_keys, int key_kind, uint64_t n_rows,
+                      uint64_t key_lo, uint64_t key_hi, uint32_t id_base, const pqps_predicate *pred,
+                      uint64_t *range, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *stream) {
+    if (!ctx || !range || !index_column || !perm || !out_count || (!sorted_keys && n_rows)) return fail(PQPS_EINVAL, "NULL argument");
+    if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
+    int rc = check_pred(cols, n_cols, pred);
+    if (rc) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    if (!probe_implies_predicate(cols, n_cols, index_column, key_kind, key_lo, key_hi, pred)) {
+        rc = launch_probe(sorted_keys, index_column->width, key_kind, n_rows, key_lo, key_hi, range, nullptr, nullptr, s);
+        if (rc) return rc;
+        return pqps_filter_gather(ctx, cols, n_cols, perm, range, n_rows, id_base, pred, out_ids, out_capacity, out_count, stream);
+    }
+    rc = ensure_scratch(ctx, 1);                                 // (base_slot: where the probe leaves the first output slot of its rows)
+    if (rc) return rc;
+    rc = launch_probe(sorted_keys, index_column->width, key_kind, n_rows, key_lo, key_hi, range, out_count, ctx->base_slot + 1, s);
+    if (rc) return rc;
+    // a workgroup per 16 K rows of the table (16 rows per thread and turn), at most 8 per CU: a narrow probe does not pay for a grid it cannot use
+    uint64_t blocks = (n_rows + 16383) / 16384;
+    const uint64_t most = (uint64_t)ctx->compute_units * 8;
+    if (blocks > most) blocks = most;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(append_range_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, perm, range, ctx->base_slot + 1, id_base, out_ids, out_capacity);
+    HIP_TRY(hipGetLastError());
+    snprintf(g_kernel, sizeof g_kernel, "append_range_kernel (the probe's rows copied: the predicate is the probed comparison)");
     return PQPS_OK;
 }
 

@@ -253,11 +253,11 @@ static int issue_calls(struct query *q, int s, pqps_ctx *ctx, void *stream) {
         for (int k = 0; k < q->n_probes; k++) {
             const struct hipIndex *ix = &sh->index[q->probes[k].index];
             uint64_t *range_dev = L->count_dev + 2;
-            TRY(pqps_index_probe(ctx, ix->keys_dev, sh->col[ix->column].width, ix->key_kind, sh->n_rows, q->probes[k].lo, q->probes[k].hi,
-                                 range_dev, stream), "index probe");
-            /* append the probe's rows that pass the complete WHERE, leaf order kept (S:441-448 + S:471) */
-            TRY(pqps_filter_gather(ctx, sp->cols, sp->n_cols, ix->perm_dev, range_dev, sh->n_rows, (uint32_t)sh->row0, sp->pred,
-                                   L->ids_dev, L->capacity_ids, L->count_dev, stream), "index filter");
+            /* the probe, then its rows that pass the complete WHERE appended, leaf order kept (S:441-448 + S:471) -- copied
+             * when the WHERE is the probed comparison itself (the shim looks at the compiled predicate) */
+            TRY(pqps_index_select(ctx, sp->cols, sp->n_cols, &sh->col[ix->column], ix->perm_dev, ix->keys_dev, ix->key_kind, sh->n_rows,
+                                  q->probes[k].lo, q->probes[k].hi, (uint32_t)sh->row0, sp->pred, range_dev,
+                                  L->ids_dev, L->capacity_ids, L->count_dev, stream), "index probe + filter");
             if (q->seg_dev[s])                                     /* where this probe's rows end on this shard */
                 TRY(pqps_copy_peer(ctx, q->seg_dev[s] + k, ctx, L->count_dev, sizeof(uint64_t), stream), "segment counter");
         }

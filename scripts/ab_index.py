@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--lo", type=int, default=1001)
     ap.add_argument("--hi", type=int, default=1001)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--select", action="store_true", help="one pqps_index_select per query (copies when the WHERE is the probed comparison) instead of probe + gather")
     args = ap.parse_args()
     pq, _ = bench.load_pkg()
     L = pq.lib()
@@ -34,12 +35,22 @@ def main():
     carr = pq.column_array([(table.ptr[args.column], w)])
     pq.check(L.pqps_index_build(ctx.h, carr, n, kind, perm, keys, None), "build")
     ctx.sync()
-    chain = [(args.column, ">=", str(args.lo)), "AND", (args.column, "<=", str(args.hi))]
+    top = 2**63 - 1 if kind == 0 else 2**31 - 1
+    if args.lo == args.hi:                                       # ONE comparison = the probe's own window: the engine's call copies
+        chain = [(args.column, "=", str(args.lo))]
+    elif args.hi >= top:
+        chain = [(args.column, ">=", str(args.lo))]
+    else:
+        chain = [(args.column, ">=", str(args.lo)), "AND", (args.column, "<=", str(args.hi))]
     pred, cols, nc, _ = table.bind(chain)
     mask = 2**64 - 1
 
     def query():
         ctx.memset(cnt, 0, 8)
+        if args.select:                                          # what the engine issues per probe (include/pqps_hip.h)
+            pq.check(L.pqps_index_select(ctx.h, cols, nc, carr, perm, keys, kind, n, args.lo & mask, args.hi & mask, 0, C.byref(pred), rng,
+                                         ids, n, cnt, None), "index select")
+            return
         pq.check(L.pqps_index_probe(ctx.h, keys, w, kind, n, args.lo & mask, args.hi & mask, rng, None), "probe")
         pq.check(L.pqps_filter_gather(ctx.h, cols, nc, perm, rng, n, 0, C.byref(pred), ids, n, cnt, None), "gather")
 
@@ -58,8 +69,9 @@ def main():
     wall = (time.perf_counter() - t0) / args.reps * 1e6
     m = C.c_uint64()
     ctx.download(C.byref(m), cnt, 8)
-    print(f"{args.column} in [{args.lo}, {args.hi}] of {n:,} rows: {m.value:,} matches; gather launch {tot / k * 1e3:.1f} us; "
-          f"memset + probe + gather back to back {wall:.1f} us per query", flush=True)
+    what = f"pqps_index_select ({L.pqps_last_kernel().decode()[:24]})" if args.select else "probe + gather"
+    print(f"{args.column} in [{args.lo}, {args.hi}] of {n:,} rows: {m.value:,} matches; " + (f"gather launch {tot / k * 1e3:.1f} us; " if k else "")
+          + f"memset + {what} back to back {wall:.1f} us per query", flush=True)
 
 
 if __name__ == "__main__":

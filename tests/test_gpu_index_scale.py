@@ -25,7 +25,7 @@ def ctx():
 
 class DeviceIndex:
     def __init__(self, ctx, table, name, signed):
-        self.ctx, self.table, self.signed = ctx, table, signed
+        self.ctx, self.table, self.signed, self.name = ctx, table, signed, name
         self.width = table.width[name]
         n = max(table.n, 1)
         self.perm = ctx.malloc(4 * n)
@@ -38,13 +38,21 @@ class DeviceIndex:
         self.ctx.free(self.keys)
 
 
-def index_select(ctx, table, probes, chain, out_ids, cap, scratch, id_base=0):
-    """probes: [(DeviceIndex, key_lo, key_hi)] in the order QPESeq would probe them."""
+def index_select(ctx, table, probes, chain, out_ids, cap, scratch, id_base=0, whole=False):
+    """probes: [(DeviceIndex, key_lo, key_hi)] in the order QPESeq would probe them.  `whole`: every probe through
+    pqps_index_select (what the engine calls: copies the probe's rows when the WHERE is the probed comparison itself)
+    instead of pqps_index_probe + pqps_filter_gather."""
     pred, cols, nc, _ = table.bind(chain)
     count_dev, range_dev = scratch, scratch + 16
     ctx.memset(count_dev, 0, 8)
     L = pq.lib()
     for ix, lo, hi in probes:
+        if whole:
+            key_col = pq.column_array([(table.ptr[ix.name], ix.width)])
+            pq.check(L.pqps_index_select(ctx.h, cols, nc, key_col, ix.perm, ix.keys, 1 if ix.signed else 0, table.n,
+                                         lo & 0xFFFFFFFFFFFFFFFF, hi & 0xFFFFFFFFFFFFFFFF, id_base, C.byref(pred), range_dev,
+                                         out_ids, cap, count_dev, None), "index select")
+            continue
         pq.check(L.pqps_index_probe(ctx.h, ix.keys, ix.width, 1 if ix.signed else 0, table.n,
                                     lo & 0xFFFFFFFFFFFFFFFF, hi & 0xFFFFFFFFFFFFFFFF, range_dev, None), "probe")
         pq.check(L.pqps_filter_gather(ctx.h, cols, nc, ix.perm, range_dev, table.n, id_base, C.byref(pred),
@@ -111,9 +119,23 @@ def test_index_mode_matches_serial_semantics_5m(ctx):
         ([("risk_level", 9, I32_MAX)], [("risk_level", ">", "8")]),                                         # empty range
     ]
     for probes, chain in cases:
-        got, k = index_select(ctx, dev, [(ix[nm], lo, hi) for nm, lo, hi in probes], chain, out, 3 * n, scratch)
         want = host_index_select(host, perms, probes, chain)
-        assert k == len(want) and np.array_equal(got, want), chain
+        for whole in (False, True):                                # probe + gather filter, and the engine's one call per probe
+            got, k = index_select(ctx, dev, [(ix[nm], lo, hi) for nm, lo, hi in probes], chain, out, 3 * n, scratch, whole=whole)
+            assert k == len(want) and np.array_equal(got, want), (chain, whole)
+    # the copy of a probe's rows (WHERE = the probed comparison): shifted row numbers, a result buffer that is too small (filled,
+    # not overrun, the count says what there was), two probes one behind the other
+    probes, chain = [("risk_level", 4, I32_MAX)], [("risk_level", ">", "3")]
+    want = host_index_select(host, perms, probes, chain)
+    got, k = index_select(ctx, dev, [(ix["risk_level"], 4, I32_MAX)], chain, out, 3 * n, scratch, id_base=1000, whole=True)
+    assert k == len(want) and np.array_equal(got, want + 1000)
+    ctx.memset(out, 0xEE, 4 * 2048)
+    got, k = index_select(ctx, dev, [(ix["risk_level"], 4, I32_MAX)], chain, out, 1001, scratch, whole=True)
+    assert k == len(want) and np.array_equal(got, want[:1001])
+    guard = np.zeros(8, dtype=np.uint32)
+    ctx.download(guard.ctypes.data, out + 4 * 1001, guard.nbytes)
+    assert np.all(guard == 0xEEEEEEEE)
+    assert pq.lib().pqps_last_kernel().decode().startswith("append_range_kernel")
     for d in ix.values():
         d.free()
     ctx.free(out)

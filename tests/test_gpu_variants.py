@@ -75,6 +75,15 @@ def test_fuller_steps_as_bit_masks_when_there_is_no_list_area():
     run_driver({"PQPS_LIST16": "0", "PQPS_EXPAND_LAG": "5", "PQPS_SUM_LAG": "2"}, "sizes", "300001", "9000001")
 
 
+def test_index_probes_evaluated_instead_of_copied():
+    """pqps_index_select copies a probe's rows when the WHERE is the probed comparison itself; PQPS_INDEX_COPY=0 sends every
+    probe through the gather filter: the reference's SELECT goldens (both index configurations) once more that way."""
+    p = subprocess.run([sys.executable, "-m", "pytest", str(q.ROOT / "tests" / "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "select_matches_reference"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PQPS_INDEX_COPY="0"), cwd=str(q.ROOT))
+    assert p.returncode == 0 and " passed" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+
+
 def test_epoch_wrap_of_the_handoff_words():
     """The hand-off words carry a 16-bit epoch; after 65535 ID queries on a scratch it starts over and the tagged arrays
     are zeroed.  A stream of queries gets there every few seconds; here the epoch starts 5 queries before the wrap."""
