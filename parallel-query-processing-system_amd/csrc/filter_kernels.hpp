@@ -48,6 +48,7 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kStepRows = 1024;             // rows per wave per step = 64 lanes x 16 rows
 constexpr int kGroupSteps = 64;             // steps per scan group (64 K rows)
 constexpr int kRplGeneric = 4;              // generic kernel: 4 consecutive rows per lane per chunk
+constexpr uint32_t kGatherParts = 16;       // gather (index mode): expander workgroups per group (each 64 / 16 = 4 steps, one per wave)
 constexpr int kSlotWords = 64;              // 16-bit entries of a step's slot in each of the two list areas of the sparse steps (128 bytes)
 
 enum Mode { MODE_IDS = 0, MODE_COUNT = 1, MODE_FLAGS = 2 };
@@ -68,6 +69,8 @@ struct EvalArgs {
     uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
     const uint32_t *cand;            // gather: candidate row numbers
     const uint64_t *range;           // gather: [begin, end) into cand, device resident
+    const void *key_col;             // gather through an index (pqps_index_select): the column the index was built on, or nullptr
+    const void *keys;                //   ... and its sorted keys: keys[i] = key_col[cand[i]], read in place of the scattered column
     // ---- ID output: hand-off words (epoch-tagged: valid when the tag is this query's) and the result ----
     uint64_t *gsum;                  // [groups]  epoch << 48 | matches of the group
     uint64_t *ssum;                  // [supers]  epoch << 48 | matches of the supergroup
@@ -522,22 +525,33 @@ __device__ __forceinline__ uint32_t eval_step_gather(CArgs &a, uint64_t step_row
         const char *base = (const char *)a.col[c];
         const int wl = a.width_log2[c];
         const uint32_t kb = a.leaf_begin[c], ke = a.leaf_begin[c + 1];
+        // The indexed column itself is not gathered: the value at candidate i is sorted key i, CONSECUTIVE in memory, whereas
+        // the candidates' rows lie all over the table (one 64-byte sector per 4-byte value: `user_id` in [1001, 1100], 5.2 M
+        // candidates of 100 M rows, moved 330 MB to look at 21 -- 135 us of a 140 us query).
+        const bool sorted = a.keys != nullptr && (const void *)base == a.key_col;      // uniform
+        if (sorted) base = (const char *)a.keys;
+        uint32_t at[R];
+#pragma unroll
+        for (int p = 0; p < R; p++) {
+            const uint64_t r = step_row0 + (uint64_t)(p / 4) * 256 + lane * kRplGeneric + (p % 4);
+            at[p] = sorted ? (uint32_t)(begin + (r < n_rows ? r : 0)) : row[p];     // (row numbers and positions: below 2^32)
+        }
         if (wl == 3) {
             uint64_t v[R];
 #pragma unroll
-            for (int p = 0; p < R; p++) v[p] = ((const uint64_t *)base)[row[p]];
+            for (int p = 0; p < R; p++) v[p] = ((const uint64_t *)base)[at[p]];
             apply_leaves<uint64_t, R>(a, kb, ke, v, idx);
         } else {
             uint32_t v[R];
             if (wl == 2) {
 #pragma unroll
-                for (int p = 0; p < R; p++) v[p] = ((const uint32_t *)base)[row[p]];
+                for (int p = 0; p < R; p++) v[p] = ((const uint32_t *)base)[at[p]];
             } else if (wl == 1) {
 #pragma unroll
-                for (int p = 0; p < R; p++) v[p] = ((const uint16_t *)base)[row[p]];
+                for (int p = 0; p < R; p++) v[p] = ((const uint16_t *)base)[at[p]];
             } else {
 #pragma unroll
-                for (int p = 0; p < R; p++) v[p] = ((const uint8_t *)base)[row[p]];
+                for (int p = 0; p < R; p++) v[p] = ((const uint8_t *)base)[at[p]];
             }
             apply_leaves<uint32_t, R>(a, kb, ke, v, idx);
         }
@@ -1709,14 +1723,16 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
     const bool leader = !shared || wave == 0;
-    // Gather (index mode): few groups, often dense -- a workgroup takes a QUARTER of a group (16 steps, 4 per wave),
-    // so that a narrow probe is spread over four times as many waves; role.index counts quarters.  Every quarter's
-    // leader settles the group for itself (and publishes its sum: the same value four times).
-    const uint32_t quarter = GATHER ? role.index % 4u : 0u;
-    const uint64_t g = GATHER ? (uint64_t)(role.index / 4u) : (shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave);
+    // Gather (index mode): few groups, often dense, and every step of the expansion is a chain of memory latencies (bit mask,
+    // candidate numbers, stores) -- a workgroup takes a SIXTEENTH of a group (kGatherParts: 4 steps, one per wave), so that a
+    // probe is spread over sixteen times as many waves (a quarter per workgroup, 4 steps per wave: `sudo_used = TRUE AND
+    // risk_level > 3` over 4.4 M candidates 140 us); role.index counts parts.  Every part's leader settles the group for itself
+    // (and publishes its sum: the same value every time).
+    const uint32_t part = GATHER ? role.index % kGatherParts : 0u;
+    const uint64_t g = GATHER ? (uint64_t)(role.index / kGatherParts) : (shared ? (uint64_t)role.index : (uint64_t)role.index * 4u + wave);
     if (g >= ex.groups) return;                                     // (the last quad of a table can be short)
     uint32_t c0 = shared ? wave * (kGroupSteps / kWaves) : 0u, c1 = shared ? c0 + kGroupSteps / kWaves : (uint32_t)kGroupSteps;
-    if constexpr (GATHER) { c0 = quarter * 16u + wave * 4u; c1 = c0 + 4u; }
+    if constexpr (GATHER) { c0 = part * (kGroupSteps / kGatherParts) + wave * (kGroupSteps / kGatherParts / kWaves); c1 = c0 + kGroupSteps / kGatherParts / kWaves; }
     bool ok = false;
     uint32_t cnts = 0;
     uint64_t group_off = 0;
@@ -1768,10 +1784,10 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         }
         __syncthreads();                                            // (waves that have left are not waited for)
         const uint32_t state = sh.state;
-        if (state == 2u) {                                          // few matches: the leader does all 64 steps (gather: its quarter)
+        if (state == 2u) {                                          // few matches: the leader does all 64 steps (gather: its workgroup's part)
             if (!leader) return;
-            c0 = GATHER ? quarter * 16u : 0u;
-            c1 = GATHER ? c0 + 16u : (uint32_t)kGroupSteps;
+            c0 = GATHER ? part * (kGroupSteps / kGatherParts) : 0u;
+            c1 = GATHER ? c0 + kGroupSteps / kGatherParts : (uint32_t)kGroupSteps;
         }
         ok = state != 0u;
         cnts = sh.counts[lane];
@@ -1803,15 +1819,15 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
         Role role;
         uint32_t layout_tiles;
         if constexpr (GATHER) {
-            // gather grid: the tiles of `layout` groups, then four expander workgroups (quarters) per group
+            // gather grid: the tiles of `layout` groups, then kGatherParts expander workgroups per group
             layout_tiles = layout * (uint32_t)(kGroupSteps / TS);
-            role.kind = uniform_u32(blockIdx.x < layout_tiles ? (uint32_t)ROLE_SCAN : (blockIdx.x - layout_tiles < 4u * layout ? (uint32_t)ROLE_EXPAND_GROUP : (uint32_t)ROLE_NONE));
+            role.kind = uniform_u32(blockIdx.x < layout_tiles ? (uint32_t)ROLE_SCAN : (blockIdx.x - layout_tiles < kGatherParts * layout ? (uint32_t)ROLE_EXPAND_GROUP : (uint32_t)ROLE_NONE));
             role.index = uniform_u32(blockIdx.x < layout_tiles ? blockIdx.x : blockIdx.x - layout_tiles);
             if (role.kind == ROLE_EXPAND_GROUP) {
                 for (Role r = role;;) {
                     expander_workgroup<GATHER, true>(args_for_expanders(), sh, ex, r);
-                    r.index += 4u * layout;
-                    if (r.index / 4u >= ex.groups) break;
+                    r.index += kGatherParts * layout;
+                    if (r.index / kGatherParts >= ex.groups) break;
                     __syncthreads();                                // the workgroup's LDS hand-over is free again
                 }
                 return;

@@ -853,7 +853,7 @@ uint32_t expand_spin_limit() {
 //   COUNT / FLAGS: the scan kernel + a one-workgroup reduction of the workgroup totals.
 //   ID output:     ONE launch -- scan tiles and, `lag` groups behind them in the grid, the expander
 //                  workgroups that turn match words into row IDs (filter_kernels.hpp).
-constexpr uint64_t kGatherGridGroups = 32;           // 512 tiles + 128 expander workgroups: resident all at once (4 workgroups per CU)
+constexpr uint64_t kGatherGridGroups = 32;           // 512 tiles (resident all at once, 2 workgroups per CU) + 512 expander workgroups behind them
 
 int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, bool gather,
                uint32_t id_base, uint32_t *out_ids, uint64_t out_cap, uint64_t *out_count, hipStream_t s,
@@ -952,9 +952,9 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.spin_limit = expand_spin_limit();
     static const uint32_t tune = [] { const char *e = tuning_env("PQPS_TUNE"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
     a.tune = ctx->opt_tune >= 0 ? (uint32_t)ctx->opt_tune : tune;
-    // gather: [tiles of `groups` groups][four expander workgroups per group]; scan: quads of tiles with their expander slot, then the trailing groups
+    // gather: [tiles of `groups` groups][kGatherParts expander workgroups per group]; scan: quads of tiles with their expander slot, then the trailing groups
     const uint64_t main_blocks = gather ? groups * tiles_per_group : ((groups + 3) / 4) * (4ull * tiles_per_group + 1);
-    const uint64_t lag = gather ? 4 * groups : trailing_groups((uint32_t)groups, a.lag);
+    const uint64_t lag = gather ? kGatherParts * groups : trailing_groups((uint32_t)groups, a.lag);
     if (main_blocks + lag > 0x7FFFFFFFull) return fail(PQPS_EINVAL, "scan of %llu rows needs more workgroups than one launch holds", (unsigned long long)rows);
     const uint64_t slack = 0;
 #ifdef PQPS_STAMPS
@@ -1302,10 +1302,15 @@ int pqps_filter_flags(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
                       0, nullptr, 0, out_count, s);
 }
 
-int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
-                       const uint32_t *cand, const uint64_t *range, uint64_t max_candidates,
-                       uint32_t id_base, const pqps_predicate *pred,
-                       uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *stream) {
+}  // extern "C"
+
+namespace {
+
+// `key_col` / `keys` (pqps_index_select): the candidates are an index's rows -- the indexed column is read from its sorted keys
+int gather_filter(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                  const uint32_t *cand, const uint64_t *range, uint64_t max_candidates,
+                  uint32_t id_base, const pqps_predicate *pred,
+                  uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *stream, const void *key_col, const void *keys) {
     if (!ctx || !out_count || !cand || !range) return fail(PQPS_EINVAL, "ctx/cand/range/out_count is NULL");
     if (!out_ids && out_capacity) return fail(PQPS_EINVAL, "out_ids is NULL");
     int rc = check_pred(cols, n_cols, pred);
@@ -1315,8 +1320,22 @@ int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
     a.n_rows = max_candidates;
     a.cand = cand;
     a.range = range;
+    a.key_col = keys ? key_col : nullptr;
+    a.keys = keys;
+    snprintf(g_kernel, sizeof g_kernel, "eval_generic_kernel<MODE_IDS, GATHER=true, NT=false>");
     return run_filter(ctx, eval_generic_kernel<MODE_IDS, true>, a, max_candidates, MODE_IDS, true,
                       id_base, out_ids, out_capacity, out_count, pick_stream(ctx, stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pqps_filter_gather(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols,
+                       const uint32_t *cand, const uint64_t *range, uint64_t max_candidates,
+                       uint32_t id_base, const pqps_predicate *pred,
+                       uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *stream) {
+    return gather_filter(ctx, cols, n_cols, cand, range, max_candidates, id_base, pred, out_ids, out_capacity, out_count, stream, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -1443,7 +1462,7 @@ int pqps_index_select(pqps_ctx *ctx, const pqps_column *cols, uint32_t n_cols, c
     if (!probe_implies_predicate(cols, n_cols, index_column, key_kind, key_lo, key_hi, pred)) {
         rc = launch_probe(sorted_keys, index_column->width, key_kind, n_rows, key_lo, key_hi, range, nullptr, nullptr, s);
         if (rc) return rc;
-        return pqps_filter_gather(ctx, cols, n_cols, perm, range, n_rows, id_base, pred, out_ids, out_capacity, out_count, stream);
+        return gather_filter(ctx, cols, n_cols, perm, range, n_rows, id_base, pred, out_ids, out_capacity, out_count, stream, index_column->data, sorted_keys);
     }
     rc = ensure_scratch(ctx, 1);                                 // (base_slot: where the probe leaves the first output slot of its rows)
     if (rc) return rc;
