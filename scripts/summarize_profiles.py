@@ -23,7 +23,7 @@ OUT = ROOT / "profiles"
 
 def short(name):
     for key, tag in (("eval_chain_kernel", "scan_eval_chain"), ("eval_spec_kernel", "scan_eval_spec"), ("eval_generic_kernel", "scan_eval_generic"),
-                     ("reduce_totals_kernel", "reduce_totals"), ("merge_slots_kernel", "merge_slots")):
+                     ("reduce_totals_kernel", "reduce_totals"), ("merge_slots_kernel", "merge_slots"), ("append_range_kernel", "append_range"), ("probe_kernel", "index_probe")):
         if key in name:
             if key in ("eval_spec_kernel", "eval_chain_kernel", "eval_generic_kernel"):
                 return tag + name[name.index("<"):name.index(">") + 1].replace(" ", "")
