@@ -64,6 +64,7 @@ struct EvalArgs {
     uint16_t *slots_hi;              // [steps][64] ... entries 64 .. 127 (two dense arrays of 128-byte lines: one array of 256-byte slots
                                      //            of which a few-percent answer fills the first half costs the scan 2 - 5 %)
     uint32_t *counts;                // [steps]     epoch << 16 | log2(RPL) << 11 | matches
+    uint64_t *tiny;                  // [steps]     epoch << 48 | up to three 16-bit entries (store_tiny): the steps with 1 - 3 matches
     uint16_t *lists;                 // [steps][1024] row lists of the fuller steps (see store_list16), or nullptr: bit masks for those
     uint8_t *out_flags;              // MODE_FLAGS
     uint64_t *partials;              // MODE_COUNT / MODE_FLAGS: [gridDim.x] workgroup totals
@@ -90,6 +91,7 @@ struct EvalArgs {
     // (32-bit fields: a 16-bit kernel argument picked by a run-time index is fetched with a VECTOR load, on the tile's path)
     uint32_t list16_min, list16_min_u8;   // a step with MORE matches than this leaves a 16-bit row list (_u8: widest predicate column 1 byte wide)
     uint32_t list_max, list_max_u8;       // a step with at most this many matches leaves them as 16-bit entries in its slot (<= kListIds)
+    uint32_t tiny_max;                    // a step with at most this many matches (<= kTinyIds; 0: never) leaves them in its tiny word
     uint32_t tune;                   // A/B switches of tuning runs (PQPS_TUNE): bit 0 = no second look ahead of early expander waves
     uint32_t accumulate;             // gather: append behind *out_count
     uint32_t epoch;                  // 1 .. 65535, unique among the queries whose words can still be around
@@ -606,6 +608,7 @@ struct alignas(16) FusedShared {
     uint64_t group_off;                                 //   ... and the group's first output slot
     uint32_t state;                                     //   ... 1 = expand now, 0 = deferred
     uint32_t tile_cnt[16];                              // scan: step counts of the tile
+    uint64_t tile_tiny[16];                             //   ... and the tiny words of its steps with at most kTinyIds matches
 };
 
 // What this launch covers: a scan of n_rows rows, or (gather) the device-side candidate range clamped
@@ -714,7 +717,11 @@ __device__ __forceinline__ void publish_tile(CArgs &a, const FusedShared &sh, co
         if (lane == 0) st_sc1(a.base_slot, *a.out_count);
         drain_stores();                                         // in memory before anything an expander waits for
     }
-    if (lane < steps_in_tile) st_sc1(a.counts + first + lane, sh.tile_cnt[lane] | (a.epoch << kEpochShift));
+    if (lane < steps_in_tile) {
+        // (the tiny word carries the epoch itself: whoever finds a count word of 1 - 3 matches looks at the tag of the step's tiny word too)
+        if (sh.tile_tiny[lane]) st_sc1(a.tiny + first + lane, sh.tile_tiny[lane]);
+        st_sc1(a.counts + first + lane, sh.tile_cnt[lane] | (a.epoch << kEpochShift));
+    }
 }
 
 // Sum duty of a scan tile.  The expander of a group needs the sums of the groups in front of it; a sum that only
@@ -796,9 +803,17 @@ constexpr uint32_t kListIds = 2 * kSlotWords; // entries of a step's two 128-byt
 // steps in both forms, and a copied step in the middle of ranked ones interrupts their run of staged IDs (`risk_level > 2`,
 // 138 per step: 947 us at 1 G rows with 128, 916 with 104 or with bit masks only; Q_B, 69 per step: 932 either way)
 constexpr uint32_t kListDefault = 104;
-enum { FORM_NONE = 0, FORM_DIRECT = 1, FORM_LIST16 = 2, FORM_MASK = 3 };
+enum { FORM_NONE = 0, FORM_DIRECT = 1, FORM_LIST16 = 2, FORM_MASK = 3, FORM_TINY = 4 };
+// A step with at most kTinyIds matches -- what a SPARSE answer consists of: S1 has 0.07 matches per step -- leaves no slot at
+// all: its entries ride in a 64-bit word of their own beside the count word (epoch << 48 | e2 << 32 | e1 << 16 | e0), stored by
+// the same lane of wave 0 in the same breath.  The tile has nothing to drain (no write-through payload before the barrier), and the
+// group's leader, which reads the count words anyway, has the IDs of such steps with the same round of loads: no slot fetch
+// between "settled" and the last ID (stamps, S1 at 100 M rows: 2.4 us of the 8 us from the last tile to the end of the launch).
+constexpr uint32_t kTinyIds = 3;
 
-__device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t rl, uint32_t lane) {
+// ranks the step's matches into `stage` (LDS, the calling wave's): entry i = the i-th matching row of the step, as its 16-bit number
+// inside the step's group
+__device__ __forceinline__ void rank_to_stage(uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t rl, uint32_t lane) {
     const uint32_t rpl = 1u << rl, chunks = 16u >> rl;              // rl = 2, 3, 4: 4, 2, 1 chunks
     uint32_t per = 0;
 #pragma unroll
@@ -818,6 +833,10 @@ __device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t s
         at += 1u << sh8;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the same wave wrote the stage)
+}
+
+__device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t step, uint32_t mbits, uint32_t cnt, uint32_t rl, uint32_t lane) {
+    rank_to_stage(stage, step, mbits, rl, lane);
     // whole 128-byte lines (entries past the count: whatever the stage held): a partly written line is a read-modify-write
     // on the memory side.  Lanes 0 .. 15: entries 0 .. 63, lanes 16 .. 31: the second line of a step with more than 64.
     if (lane < (cnt > 64u ? 32u : 16u))
@@ -835,6 +854,7 @@ __device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t s
 // (`step_form` must agree between the tile that writes and the expander that reads: both see the count word.)
 __device__ __forceinline__ uint32_t step_form(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
     if (cnt == 0u) return FORM_NONE;
+    if (cnt <= a.tiny_max) return FORM_TINY;
     if (cnt <= (rpl_log2 >= 4u ? a.list_max_u8 : a.list_max)) return FORM_DIRECT;
 #ifndef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
     if (a.lists != nullptr && cnt > (rpl_log2 >= 4u ? a.list16_min_u8 : a.list16_min)) return FORM_LIST16;
@@ -897,6 +917,13 @@ __device__ __forceinline__ void store_list16(CArgs &a, uint16_t *stage, uint64_t
 __device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
     const uint32_t form = step_form(a, cnt, rpl_log2);              // uniform
+    uint64_t tiny = 0;
+    if (form == FORM_TINY) {
+        uint16_t *stage = &sh.mask[threadIdx.x >> 6][0][0];
+        rank_to_stage(stage, step, mbits, rpl_log2, lane);
+        tiny = ((uint64_t)a.epoch << kWordEpochShift) | ((uint64_t)stage[0] | ((uint64_t)stage[1] << 16) | ((uint64_t)stage[2] << 32));   // (entries past the count: whatever the stage held)
+    }
+    if (lane == 0) sh.tile_tiny[slot] = tiny;
     if (form == FORM_DIRECT) store_list(a, &sh.mask[threadIdx.x >> 6][0][0], step, mbits, cnt, rpl_log2, lane);
     else if (form == FORM_LIST16) {
         uint16_t *stage = (uint16_t *)sh.stage[threadIdx.x >> 6];                  // 2 KB per wave: 1024 entries
@@ -1284,11 +1311,12 @@ __device__ __forceinline__ bool word_valid(CArgs &a, uint64_t w) { return (uint3
 // (which costs ~250 vector instructions) when it has appeared.
 template <int NEAR>
 __device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
-                                               uint32_t &cw, uint64_t &psum, uint64_t &own_super, const uint64_t *&watch) {
+                                               uint32_t &cw, uint64_t &tw, uint64_t &psum, uint64_t &own_super, const uint64_t *&watch) {
     uint32_t now = 0;
     const uint64_t step = g * kGroupSteps + lane;
     uint32_t c = a.epoch << kEpochShift;
-    if ((left & 1u) && step < ex.steps) c = ld_sc1(a.counts + step);
+    uint64_t t = 0;                                                 // the step's tiny word (looked at if the count word says 1 - kTinyIds matches)
+    if ((left & 1u) && step < ex.steps) { c = ld_sc1(a.counts + step); t = ld_sc1(a.tiny + step); }
     if (left & 2u) {                                                // uniform
         const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
         const uint64_t far = sg > (uint64_t)NEAR ? sg - NEAR : 0;   // supergroups [0, far): by their words only
@@ -1341,7 +1369,8 @@ __device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint6
         }
     }
     if (left & 1u) {
-        if (__all((c >> kEpochShift) == a.epoch)) cw = c; else now |= 1u;
+        const bool there = (c >> kEpochShift) == a.epoch && (word_form(a, c) != (uint32_t)FORM_TINY || word_valid(a, t));
+        if (__all(there)) { cw = c; tw = t; } else now |= 1u;
     }
     return now;
 }
@@ -1425,17 +1454,33 @@ struct LeaderPrefetch { FusedShared *sh; uint32_t park; uint32_t pre; uint64_t m
 template <bool GATHER>
 __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
                                              uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0,
-                                             uint64_t pre_mask = 0) {
+                                             uint64_t pre_mask = 0, uint64_t tiny_span = 0, uint64_t tw = 0) {
     const uint32_t my_cnt = cw & kCountMask;
     const uint32_t incl = wave_incl_scan_u32(my_cnt);
     const uint64_t my_off = group_off + (incl - my_cnt);
     if (g + 1 == ex.groups && c0 == 0 && lane == 63) *a.out_count = group_off + incl;
     const uint64_t span = (c1 >= 64 ? ~0ull : ((1ull << c1) - 1ull)) & ~((1ull << c0) - 1ull);
-    const uint64_t all_nonempty = __ballot(my_cnt != 0) & span;     // non-empty steps of the range (wave-uniform)
-    if (!all_nonempty) return;
-    // Steps that left 16-bit entries in their slots (what a sparse or a few-percent answer consists of): copied first, up to
-    // 16 steps to a round of loads, every step at its own output offset -- no LDS, no ring, no order among them.
     const uint32_t form = word_form(a, cw);
+    // Steps with 1 - kTinyIds matches: their entries came with the count words (`tw`, lane l = step l): lane l stores its
+    // step's IDs itself -- three store instructions for the whole group, no load.  The steps of `tiny_span` are this wave's to do.
+    const uint64_t tiny = __ballot(form == (uint32_t)FORM_TINY);
+    if (tiny & tiny_span) {                                         // uniform
+        const uint32_t gbase = (uint32_t)(g * kGroupSteps * kStepRows);
+        const bool mine = form == (uint32_t)FORM_TINY && ((tiny_span >> lane) & 1ull) != 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kTinyIds; i++) {
+            const uint32_t e = (uint32_t)(tw >> (16u * i)) & 0xFFFFu;
+            if (mine && i < my_cnt && my_off + i < a.out_cap) {
+                uint32_t id = gbase + e;
+                if constexpr (GATHER) id = a.cand[ex.begin + id];   // (a listed position lies inside the probed range)
+                st_id(a.out_ids + my_off + i, id + a.id_base);
+            }
+        }
+    }
+    const uint64_t all_nonempty = __ballot(my_cnt != 0) & span & ~tiny;     // non-empty steps of the range that left something to fetch (wave-uniform)
+    if (!all_nonempty) return;
+    // Steps that left 16-bit entries in their slots (what a few-percent answer consists of): copied first, up to
+    // 16 steps to a round of loads, every step at its own output offset -- no LDS, no ring, no order among them.
     const uint64_t direct = __ballot(form == FORM_DIRECT) & span;
     if (direct) {                                                   // uniform
         // entries that have a place in the caller's buffer (a result that does not fit is cut off, the count says so)
@@ -1558,7 +1603,7 @@ constexpr int kNearGroups = 6;     // supergroups in front whose group sums are 
 
 template <int NEAR>
 __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
-                                             uint32_t &cw, uint64_t &psum, bool final_word = false, LeaderPrefetch *lp = nullptr) {
+                                             uint32_t &cw, uint64_t &tw, uint64_t &psum, bool final_word = false, LeaderPrefetch *lp = nullptr) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
     uint64_t own_super = 0;
     uint32_t left = 3u;
@@ -1571,8 +1616,8 @@ __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_
     const uint64_t deadline = long_wait ? wall_clock64() + kRecoverTicks : 0ull;
     for (uint32_t spins = 0;; spins++) {
         const uint64_t *watch = nullptr;
-        left = light ? poll_group<0>(a, ex, g, lane, left, cw, psum, own_super, watch)
-                     : poll_group<NEAR>(a, ex, g, lane, left, cw, psum, own_super, watch);
+        left = light ? poll_group<0>(a, ex, g, lane, left, cw, tw, psum, own_super, watch)
+                     : poll_group<NEAR>(a, ex, g, lane, left, cw, tw, psum, own_super, watch);
         light = false;
         PQPS_STAMP_VALUE(a, g, 4, (uint64_t)spins + 1);
         if (!(left & 1u) && !sum_out) {
@@ -1694,6 +1739,23 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
                 const uint32_t st = (uint32_t)__builtin_ctzll(rest);
                 const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
                 const uint64_t step = g * kGroupSteps + st;
+                if (word_form(a, cwi) == FORM_TINY) {               // 1 - kTinyIds matches: in the step's tiny word
+                    if (r.pending) ring_flush(a, ring, r, lane, r.pending);
+                    const uint32_t n = cwi & kCountMask;
+                    uint64_t t = ld_sc1(a.tiny + step);
+                    for (const uint64_t deadline = wall_clock64() + kRecoverTicks; !word_valid(a, t) && wall_clock64() < deadline;) {   // (stored beside the count word)
+                        __builtin_amdgcn_s_sleep(8);
+                        t = ld_sc1(a.tiny + step);
+                    }
+                    if (!word_valid(a, t)) { if (lane == 0) report_gave_up(a); }
+                    else if (lane < n && r.pos + lane < a.out_cap) {
+                        uint32_t id = (uint32_t)(g * kGroupSteps * kStepRows) + ((uint32_t)(t >> (16u * lane)) & 0xFFFFu);
+                        if constexpr (GATHER) id = a.cand[ex.begin + id];
+                        st_id(a.out_ids + r.pos + lane, id + a.id_base);
+                    }
+                    r.pos += n;
+                    continue;
+                }
                 if (word_form(a, cwi) == FORM_DIRECT) {             // 16-bit entries in its slot: a copy (every lane: this step's limit and offset)
                     if (r.pending) ring_flush(a, ring, r, lane, r.pending);
                     const uint32_t n = cwi & kCountMask;
@@ -1736,6 +1798,7 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
     bool ok = false;
     uint32_t cnts = 0;
     uint64_t group_off = 0;
+    uint64_t tiny_words = 0;                                        // leaders: lane l = the tiny word of step l (settle_group)
     if (shared && !leader && !LOOPED) {
         // A group with few matches is its leader's alone: the other three waves leave as soon as they know (from the
         // group's sum, which a tile has published long ago unless this is the end of the table) -- a wave that waits
@@ -1765,7 +1828,7 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         // (gather: the whole grid is resident at once, so a wait can only fail if a tile never ran -- no second
         // chance through the recovery pass there, the wait is long and its failure sets the status word)
         LeaderPrefetch lp{&sh, wave, pre, pre_mask};
-        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, psum, GATHER, (!GATHER && shared) ? &lp : nullptr);
+        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, tiny_words, psum, GATHER, (!GATHER && shared) ? &lp : nullptr);
         pre = lp.pre;
         pre_mask = lp.mask;
         __builtin_amdgcn_s_setprio(0);
@@ -1793,7 +1856,11 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         cnts = sh.counts[lane];
         group_off = sh.group_off;
     }
-    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask);
+    // The steps with 1 - kTinyIds matches are their group's LEADER's, whichever wave the other steps around them belong to: it has
+    // their entries from the look that settled the group (gather: every part's leader settles for itself -- its part's steps).
+    uint64_t tiny_span = 0;
+    if (leader) tiny_span = !GATHER ? ~0ull : (((1ull << (kGroupSteps / kGatherParts)) - 1ull) << (part * (kGroupSteps / kGatherParts)));
+    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask, tiny_span, tiny_words);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
     // the last group's leader looks after the groups others gave up on (if any), once all of them are past their waits
     if constexpr (!GATHER)

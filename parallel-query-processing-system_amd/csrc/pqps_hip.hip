@@ -466,6 +466,7 @@ struct pqps_ctx {
     uint16_t *masks;            // [steps][64] match words (steps that left a bit mask)
     uint16_t *slots, *slots_hi; // [steps][kSlotWords] each: 16-bit entries 0 .. 63 / 64 .. 127 of the steps with at most kListIds matches
     uint32_t *counts;           // [steps] step counts; all zero between queries
+    uint64_t *tiny;             // [steps] tiny words: the entries of the steps with 1 - 3 matches (epoch-tagged)
     uint16_t *lists;            // [list_steps][1024] 16-bit row lists of the fuller steps (ID scans; allocated with the first one)
     uint64_t list_steps;
     bool lists_refused;         // the list area did not fit into device memory: bit masks for every step from then on
@@ -486,7 +487,7 @@ struct pqps_ctx {
     uint64_t *check_dev;        // [2] pqps_ids_checksum
     // per-context overrides of the launch parameters (pqps_ctx_set_option: A/B runs inside ONE process, where the physical
     // placement of the table is the same for every variant); -1 = the default
-    long opt_list16, opt_list16_min, opt_list16_min_u8, opt_list_max, opt_list_max_u8, opt_expand_lag, opt_sum_lag, opt_tune;
+    long opt_list16, opt_list16_min, opt_list16_min_u8, opt_list_max, opt_list_max_u8, opt_tiny_max, opt_expand_lag, opt_sum_lag, opt_tune;
     void *sort_tmp;
     size_t sort_tmp_bytes;
     // optional per-launch timing (bench.py roofline)
@@ -506,10 +507,10 @@ hipStream_t pick_stream(pqps_ctx *ctx, void *stream) {
 }
 
 void free_scratch(pqps_ctx *ctx) {
-    void *all[] = {ctx->masks, ctx->slots, ctx->slots_hi, ctx->counts, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials, ctx->lists};
+    void *all[] = {ctx->masks, ctx->slots, ctx->slots_hi, ctx->counts, ctx->tiny, ctx->gsum, ctx->ssum, ctx->deferred, ctx->ctl, ctx->base_slot, ctx->partials, ctx->lists};
     for (void *p : all) if (p) (void)hipFree(p);
     ctx->lists = nullptr; ctx->list_steps = 0;
-    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->tiny = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->scratch_steps = 0;
 }
@@ -517,6 +518,7 @@ void free_scratch(pqps_ctx *ctx) {
 // Epoch 0 = "never written": what every tagged word holds after this.
 int zero_tagged_words(pqps_ctx *ctx, hipStream_t s) {
     HIP_TRY(hipMemsetAsync(ctx->counts, 0, ctx->scratch_steps * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(ctx->tiny, 0, ctx->scratch_steps * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(ctx->gsum, 0, ctx->hand_groups * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(ctx->ssum, 0, (ctx->hand_groups / kSuperGroups + 1) * sizeof(uint64_t), s));
     HIP_TRY(hipMemsetAsync(ctx->deferred, 0, ctx->hand_groups * sizeof(uint32_t), s));
@@ -539,6 +541,7 @@ int ensure_scratch(pqps_ctx *ctx, uint64_t steps) {
     HIP_TRY(hipMalloc((void **)&ctx->slots, cap * kSlotWords * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->slots_hi, cap * kSlotWords * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&ctx->counts, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&ctx->tiny, cap * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&ctx->gsum, groups * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&ctx->ssum, (groups / kSuperGroups + 1) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&ctx->deferred, groups * sizeof(uint32_t)));
@@ -875,6 +878,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.slots = ctx->slots;
     a.slots_hi = ctx->slots_hi;
     a.counts = ctx->counts;
+    a.tiny = ctx->tiny;
     a.partials = ctx->partials;
     const bool timed = ctx->timing && ctx->timed < kMaxTimedLaunches;
     if (mode != MODE_IDS) {
@@ -936,6 +940,10 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         static const long env_max = [] { const char *e = getenv("PQPS_LIST_MAX"); return e ? strtol(e, nullptr, 0) : -1l; }();
         const uint32_t m0 = ctx->opt_list_max >= 0 ? (uint32_t)ctx->opt_list_max : (env_max >= 0 ? (uint32_t)env_max : kListDefault);
         const uint32_t m1 = ctx->opt_list_max_u8 >= 0 ? (uint32_t)ctx->opt_list_max_u8 : 0u;
+        // PQPS_TINY_MAX (tests): 0 = no step leaves its entries in a tiny word
+        static const long env_tiny = [] { const char *e = getenv("PQPS_TINY_MAX"); return e ? strtol(e, nullptr, 0) : -1l; }();
+        const uint32_t t0 = ctx->opt_tiny_max >= 0 ? (uint32_t)ctx->opt_tiny_max : (env_tiny >= 0 ? (uint32_t)env_tiny : kTinyIds);
+        a.tiny_max = t0 < kTinyIds ? t0 : kTinyIds;
         a.list_max = m0 < kListIds ? m0 : kListIds;
         a.list_max_u8 = m1 < kListIds ? m1 : kListIds;
     }
@@ -1050,13 +1058,13 @@ int create_ctx(int device, bool lane, pqps_ctx **out) {
     ctx->device = device;
     ctx->compute_units = prop.multiProcessorCount;
     ctx->scratch_steps = 0;
-    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
+    ctx->masks = nullptr; ctx->slots = nullptr; ctx->slots_hi = nullptr; ctx->counts = nullptr; ctx->tiny = nullptr; ctx->gsum = nullptr; ctx->ssum = nullptr; ctx->deferred = nullptr;
     ctx->ctl = nullptr; ctx->base_slot = nullptr; ctx->partials = nullptr;
     ctx->lists = nullptr; ctx->list_steps = 0; ctx->lists_refused = false;
     ctx->status_host = nullptr; ctx->status_dev = nullptr;
     ctx->parity = 0; ctx->epoch = 0; ctx->hand_groups = 0; ctx->needs_reset.store(false);
     ctx->check_dev = nullptr;
-    ctx->opt_list16 = ctx->opt_list16_min = ctx->opt_list16_min_u8 = ctx->opt_list_max = ctx->opt_list_max_u8 = ctx->opt_expand_lag = ctx->opt_sum_lag = ctx->opt_tune = -1;
+    ctx->opt_list16 = ctx->opt_list16_min = ctx->opt_list16_min_u8 = ctx->opt_list_max = ctx->opt_list_max_u8 = ctx->opt_tiny_max = ctx->opt_expand_lag = ctx->opt_sum_lag = ctx->opt_tune = -1;
     ctx->sort_tmp = nullptr;
     ctx->sort_tmp_bytes = 0;
     ctx->timing = false;
@@ -1177,7 +1185,7 @@ int pqps_ctx_set_option(pqps_ctx *ctx, const char *name, long value) {
     if (!ctx || !name) return fail(PQPS_EINVAL, "NULL argument");
     struct { const char *name; long *slot; } opts[] = {
         {"list16", &ctx->opt_list16}, {"list16_min", &ctx->opt_list16_min}, {"list16_min_u8", &ctx->opt_list16_min_u8},
-        {"list_max", &ctx->opt_list_max}, {"list_max_u8", &ctx->opt_list_max_u8},
+        {"list_max", &ctx->opt_list_max}, {"list_max_u8", &ctx->opt_list_max_u8}, {"tiny_max", &ctx->opt_tiny_max},
         {"expand_lag", &ctx->opt_expand_lag}, {"sum_lag", &ctx->opt_sum_lag}, {"tune", &ctx->opt_tune},
     };
     for (auto &o : opts)

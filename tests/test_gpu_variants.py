@@ -67,6 +67,18 @@ def test_steps_with_and_without_entries_in_their_slots(list_max):
     run_driver(dict(env, PQPS_LIST16="0"), "sizes", "4097", "300001", str((1 << 21) + 17))
 
 
+def test_sparse_steps_without_tiny_words():
+    """A step with 1 - 3 matches leaves its entries in a tiny word beside its count word (the group's leader has them with the
+    look that settles the group); PQPS_TINY_MAX=0: such steps leave entries in their slots like fuller ones.  Every shape,
+    the sizes, expanders among the tiles, the recovery pass -- the defaults of every other test in this file run WITH tiny words."""
+    env = {"PQPS_TINY_MAX": "0"}
+    run_driver(env, "shapes", "70001")
+    run_driver(env, "sizes", "1", "4097", "300001", str((1 << 21) + 17))
+    run_driver(dict(env, PQPS_EXPAND_LAG="5", PQPS_SUM_LAG="2"), "sizes", "65537", "300001", "9000001")
+    run_driver(dict(env, PQPS_EXPAND_SPIN_LIMIT="0", PQPS_SUM_LAG="2000000000", PQPS_EXPAND_LAG="0"), "sizes", "65537", "300001")
+    run_driver({"PQPS_TINY_MAX": "1"}, "sizes", "4097", "300001")
+
+
 def test_fuller_steps_as_bit_masks_when_there_is_no_list_area():
     """Steps with more than 104 matches leave 16-bit row lists in the context's list area (2 bytes per table row); a
     context that cannot get one (or PQPS_LIST16=0) keeps the bit masks and the ranking expansion for them."""
