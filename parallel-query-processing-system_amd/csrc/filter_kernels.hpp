@@ -709,7 +709,7 @@ __device__ __forceinline__ bool expanders_past_their_wait(CArgs &a, uint64_t gro
 // match-word stores and passed the workgroup's barrier; wave 0 publishes the count words with the query's
 // epoch: an expander that finds all count words of its group tagged with it knows the group's match words are
 // in memory.  One store instruction, no atomic, nothing to wait for.
-template <int TS>
+template <int TS, bool TINY = true>
 __device__ __forceinline__ void publish_tile(CArgs &a, const FusedShared &sh, const Extent &ex, uint64_t tile, uint32_t lane) {
     const uint64_t first = tile * TS;
     const uint32_t steps_in_tile = ex.steps - first < (uint64_t)TS ? (uint32_t)(ex.steps - first) : (uint32_t)TS;
@@ -719,7 +719,7 @@ __device__ __forceinline__ void publish_tile(CArgs &a, const FusedShared &sh, co
     }
     if (lane < steps_in_tile) {
         // (the tiny word carries the epoch itself: whoever finds a count word of 1 - 3 matches looks at the tag of the step's tiny word too)
-        if (sh.tile_tiny[lane]) st_sc1(a.tiny + first + lane, sh.tile_tiny[lane]);
+        if constexpr (TINY) { if (sh.tile_tiny[lane]) st_sc1(a.tiny + first + lane, sh.tile_tiny[lane]); }
         st_sc1(a.counts + first + lane, sh.tile_cnt[lane] | (a.epoch << kEpochShift));
     }
 }
@@ -854,7 +854,7 @@ __device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t s
 // (`step_form` must agree between the tile that writes and the expander that reads: both see the count word.)
 __device__ __forceinline__ uint32_t step_form(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
     if (cnt == 0u) return FORM_NONE;
-    if (cnt <= a.tiny_max) return FORM_TINY;
+    if (rpl_log2 < 4u && cnt <= a.tiny_max) return FORM_TINY;      // (not for 1-byte predicates: the host asks for none there, and their tiles are spared the code)
     if (cnt <= (rpl_log2 >= 4u ? a.list_max_u8 : a.list_max)) return FORM_DIRECT;
 #ifndef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
     if (a.lists != nullptr && cnt > (rpl_log2 >= 4u ? a.list16_min_u8 : a.list16_min)) return FORM_LIST16;
@@ -913,6 +913,12 @@ __device__ __forceinline__ void store_list16(CArgs &a, uint16_t *stage, uint64_t
         }
 }
 
+// Start of a scan tile: no step of it has a tiny word yet (only the steps with 1 - kTinyIds matches write theirs; a wave's
+// LDS accesses keep their order, and a tile's waves meet at its barrier before wave 0 reads the words).
+__device__ __forceinline__ void zero_tiny_words(FusedShared &sh, uint32_t first_slot, uint32_t n_slots) {
+    if ((threadIdx.x & 63u) < n_slots) sh.tile_tiny[first_slot + (threadIdx.x & 63u)] = 0;
+}
+
 // One wave's share of a scan tile: count word into LDS, match words (if any) to memory.
 __device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_t slot, uint64_t step, uint32_t cnt,
                                               uint32_t mbits, uint32_t rpl_log2, uint32_t lane) {
@@ -922,8 +928,8 @@ __device__ __forceinline__ void tile_step_out(CArgs &a, FusedShared &sh, uint32_
         uint16_t *stage = &sh.mask[threadIdx.x >> 6][0][0];
         rank_to_stage(stage, step, mbits, rpl_log2, lane);
         tiny = ((uint64_t)a.epoch << kWordEpochShift) | ((uint64_t)stage[0] | ((uint64_t)stage[1] << 16) | ((uint64_t)stage[2] << 32));   // (entries past the count: whatever the stage held)
+        if (lane == 0) sh.tile_tiny[slot] = tiny;               // (the other steps' words stay zero: zero_tiny_words)
     }
-    if (lane == 0) sh.tile_tiny[slot] = tiny;
     if (form == FORM_DIRECT) store_list(a, &sh.mask[threadIdx.x >> 6][0][0], step, mbits, cnt, rpl_log2, lane);
     else if (form == FORM_LIST16) {
         uint16_t *stage = (uint16_t *)sh.stage[threadIdx.x >> 6];                  // 2 KB per wave: 1024 entries
@@ -1316,7 +1322,7 @@ __device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint6
     const uint64_t step = g * kGroupSteps + lane;
     uint32_t c = a.epoch << kEpochShift;
     uint64_t t = 0;                                                 // the step's tiny word (looked at if the count word says 1 - kTinyIds matches)
-    if ((left & 1u) && step < ex.steps) { c = ld_sc1(a.counts + step); t = ld_sc1(a.tiny + step); }
+    if ((left & 1u) && step < ex.steps) { c = ld_sc1(a.counts + step); if (a.tiny_max) t = ld_sc1(a.tiny + step); }    // (tiny_max: uniform)
     if (left & 2u) {                                                // uniform
         const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
         const uint64_t far = sg > (uint64_t)NEAR ? sg - NEAR : 0;   // supergroups [0, far): by their words only
@@ -1908,6 +1914,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (GATHER ? 2 : 4) : 1) vo
         for (uint64_t tile = role.index; tile * TS < ex.steps; tile += layout_tiles) {
             const uint64_t step = tile * TS + wv;
             const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, (uint32_t)tile, wv, lane);
+            zero_tiny_words(sh, wv, 1);
             uint32_t cnt = 0;
             if (step < ex.steps) {
                 const uint64_t step_row0 = step * kStepRows;
@@ -2218,7 +2225,7 @@ struct RawStep {
     asm volatile("" :: "s"((a).n_rows), "s"((a).col[0]), "s"((a).col[1]), "s"((a).col[2]), "s"(gridDim.x),  \
                  "s"((a).masks), "s"((a).chain), "s"((a).chain_want), "s"((a).negmask), "s"((a).lag), "s"((a).sum_lag), "s"((a).counts),     \
                  "s"((uint32_t)(a).leaf_begin[0]), "s"((uint32_t)(a).leaf_begin[1]), "s"((uint32_t)(a).leaf_begin[2]), \
-                 "s"((uint32_t)(a).leaf_begin[3]), "s"((a).lists), "s"((a).list_max), "s"((a).list_max_u8), "s"((a).list16_min), "s"((a).list16_min_u8))
+                 "s"((uint32_t)(a).leaf_begin[3]), "s"((a).lists), "s"((a).list_max), "s"((a).list_max_u8), "s"((a).list16_min), "s"((a).list16_min_u8), "s"((a).tiny_max))
 
 // General tree of <= 6 leaves (row-mask path).
 template <int MODE, int W0, int W1, int W2, bool NT>
@@ -2244,6 +2251,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
         const uint64_t step = (uint64_t)role.index * TS + wv;
         SumDuty duty;
         uint32_t cnt = 0;
+        if constexpr (RPL < 16) zero_tiny_words(sh, wv, 1);
         if (step < ex.steps) {
             RawStep<W0, W1, W2, RPL, U> A;
             A.template load<NT>(a, step * kStepRows + lane_off);
@@ -2258,7 +2266,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
         }
         if (cnt) drain_stores();
         __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
+        if (wv == 0) { publish_tile<TS, (RPL < 16)>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
@@ -2319,6 +2327,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void
         for (int i = 0; i < S; i++)
             if (step0 + i < ex.steps) A[i].template load<NT>(a, (step0 + i) * kStepRows + lane_off);        // uniform guard
         const SumDuty duty = sum_duty_load<kGroupSteps / TS>(a, role.index, wv, lane);   // behind the column loads, consumed after the tile's work
+        if constexpr (RPL < 16) zero_tiny_words(sh, wv * S, S);
         uint32_t any = 0;
 #pragma unroll
         for (int i = 0; i < S; i++) {
@@ -2338,7 +2347,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void
         }
         if (any) drain_stores();
         __syncthreads();
-        if (wv == 0) { publish_tile<TS>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
+        if (wv == 0) { publish_tile<TS, (RPL < 16)>(a, sh, ex, role.index, lane); sum_duty_finish(a, duty, lane); PQPS_STAMP_TILE(a, role.index); }
     } else {
         const uint64_t wave = (uint64_t)blockIdx.x * kWaves + wv;
         const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
