@@ -113,7 +113,7 @@ void pqps_ctx_destroy(pqps_ctx *ctx);
 int  pqps_ctx_reserve(pqps_ctx *ctx, uint64_t n_rows);
 int  pqps_ctx_sync(pqps_ctx *ctx, void *stream);
 /* Launch parameters of this context's ID queries (tests, A/B runs inside one process): "list16" 0 / 1 (the list area),
- * "list16_min" / "list16_min_u8" (a step with more matches leaves a 16-bit list), "list_max" / "list_max_u8" (a step with at
+ * "list16_min" / "list16_min_u8" (a step with more matches leaves a 16-bit list), "list_max" (a step with at
  * most this many matches leaves 16-bit entries in its slot; 0 .. 128), "tiny_max" (... in its tiny word; 0 .. 3),
  * "expand_lag" / "sum_lag" (groups),
  * "tune" (bits); value < 0 restores the default. */

@@ -854,8 +854,10 @@ __device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t s
 // (`step_form` must agree between the tile that writes and the expander that reads: both see the count word.)
 __device__ __forceinline__ uint32_t step_form(CArgs &a, uint32_t cnt, uint32_t rpl_log2) {
     if (cnt == 0u) return FORM_NONE;
-    if (rpl_log2 < 4u && cnt <= a.tiny_max) return FORM_TINY;      // (not for 1-byte predicates: the host asks for none there, and their tiles are spared the code)
-    if (cnt <= (rpl_log2 >= 4u ? a.list_max_u8 : a.list_max)) return FORM_DIRECT;
+    if (rpl_log2 < 4u) {                                            // (not for 1-byte predicates -- a step is 1 KB of input there: their kernels are spared the code)
+        if (cnt <= a.tiny_max) return FORM_TINY;
+        if (cnt <= a.list_max) return FORM_DIRECT;
+    }
 #ifndef PQPS_NO_LIST16   /* experiments: what the kernels cost without the list code in them */
     if (a.lists != nullptr && cnt > (rpl_log2 >= 4u ? a.list16_min_u8 : a.list16_min)) return FORM_LIST16;
 #endif
@@ -1315,14 +1317,17 @@ __device__ __forceinline__ bool word_valid(CArgs &a, uint64_t w) { return (uint3
 // `watch` (set when the front is still open): the LAST of the sum words found missing -- sums appear roughly in
 // ascending order, so the caller can wait for that one word with one-load looks and come back for a full one
 // (which costs ~250 vector instructions) when it has appeared.
-template <int NEAR>
+template <int NEAR, bool NARROW = false>                        // NARROW: a kernel for 1-byte predicates -- no step of it has a tiny word or entries in its slot
 __device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t left,
                                                uint32_t &cw, uint64_t &tw, uint64_t &psum, uint64_t &own_super, const uint64_t *&watch) {
     uint32_t now = 0;
     const uint64_t step = g * kGroupSteps + lane;
     uint32_t c = a.epoch << kEpochShift;
     uint64_t t = 0;                                                 // the step's tiny word (looked at if the count word says 1 - kTinyIds matches)
-    if ((left & 1u) && step < ex.steps) { c = ld_sc1(a.counts + step); if (a.tiny_max) t = ld_sc1(a.tiny + step); }    // (tiny_max: uniform)
+    if ((left & 1u) && step < ex.steps) {
+        c = ld_sc1(a.counts + step);
+        if constexpr (!NARROW) { if (a.tiny_max) t = ld_sc1(a.tiny + step); }      // (tiny_max: uniform)
+    }
     if (left & 2u) {                                                // uniform
         const uint64_t sg = g / kSuperGroups, g_in = g % kSuperGroups;
         const uint64_t far = sg > (uint64_t)NEAR ? sg - NEAR : 0;   // supergroups [0, far): by their words only
@@ -1375,7 +1380,7 @@ __device__ __forceinline__ uint32_t poll_group(CArgs &a, const Extent &ex, uint6
         }
     }
     if (left & 1u) {
-        const bool there = (c >> kEpochShift) == a.epoch && (word_form(a, c) != (uint32_t)FORM_TINY || word_valid(a, t));
+        const bool there = (c >> kEpochShift) == a.epoch && (NARROW || word_form(a, c) != (uint32_t)FORM_TINY || word_valid(a, t));
         if (__all(there)) { cw = c; tw = t; } else now |= 1u;
     }
     return now;
@@ -1457,7 +1462,7 @@ struct LeaderPrefetch { FusedShared *sh; uint32_t park; uint32_t pre; uint64_t m
 // The calling wave turns the match words of steps [c0, c1) of group g (both multiples of 16) into row IDs
 // (`park` = its LDS slice; `cw` = lane l holds the count word of step l; `group_off` = the group's first output slot).
 // `pre` = what prefetch_own_steps returned for [c0, c0 + 16) (0: nothing is on its way).
-template <bool GATHER>
+template <bool GATHER, bool NARROW = false>
 __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Extent &ex, uint64_t g, uint32_t lane, uint32_t c0,
                                              uint32_t c1, uint32_t park, uint32_t cw, uint64_t group_off, uint32_t pre = 0,
                                              uint64_t pre_mask = 0, uint64_t tiny_span = 0, uint64_t tw = 0) {
@@ -1469,7 +1474,7 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
     const uint32_t form = word_form(a, cw);
     // Steps with 1 - kTinyIds matches: their entries came with the count words (`tw`, lane l = step l): lane l stores its
     // step's IDs itself -- three store instructions for the whole group, no load.  The steps of `tiny_span` are this wave's to do.
-    const uint64_t tiny = __ballot(form == (uint32_t)FORM_TINY);
+    const uint64_t tiny = NARROW ? 0ull : __ballot(form == (uint32_t)FORM_TINY);
     if (tiny & tiny_span) {                                         // uniform
         const uint32_t gbase = (uint32_t)(g * kGroupSteps * kStepRows);
         const bool mine = form == (uint32_t)FORM_TINY && ((tiny_span >> lane) & 1ull) != 0;
@@ -1487,7 +1492,7 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
     if (!all_nonempty) return;
     // Steps that left 16-bit entries in their slots (what a few-percent answer consists of): copied first, up to
     // 16 steps to a round of loads, every step at its own output offset -- no LDS, no ring, no order among them.
-    const uint64_t direct = __ballot(form == FORM_DIRECT) & span;
+    const uint64_t direct = NARROW ? 0ull : __ballot(form == FORM_DIRECT) & span;
     if (direct) {                                                   // uniform
         // entries that have a place in the caller's buffer (a result that does not fit is cut off, the count says so)
         const uint64_t room = my_off < a.out_cap ? a.out_cap - my_off : 0ull;
@@ -1607,7 +1612,7 @@ __device__ __forceinline__ void expand_range(CArgs &a, FusedShared &sh, const Ex
 // It first publishes the sums that are missing, in ascending order, then expands the deferred groups.
 constexpr int kNearGroups = 6;     // supergroups in front whose group sums are read along with their words when a word is missing
 
-template <int NEAR>
+template <int NEAR, bool NARROW = false>
 __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_t g, uint32_t lane, uint32_t limit, bool recovery,
                                              uint32_t &cw, uint64_t &tw, uint64_t &psum, bool final_word = false, LeaderPrefetch *lp = nullptr) {
     const uint64_t tag = (uint64_t)a.epoch << kWordEpochShift;
@@ -1622,8 +1627,8 @@ __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_
     const uint64_t deadline = long_wait ? wall_clock64() + kRecoverTicks : 0ull;
     for (uint32_t spins = 0;; spins++) {
         const uint64_t *watch = nullptr;
-        left = light ? poll_group<0>(a, ex, g, lane, left, cw, tw, psum, own_super, watch)
-                     : poll_group<NEAR>(a, ex, g, lane, left, cw, tw, psum, own_super, watch);
+        left = light ? poll_group<0, NARROW>(a, ex, g, lane, left, cw, tw, psum, own_super, watch)
+                     : poll_group<NEAR, NARROW>(a, ex, g, lane, left, cw, tw, psum, own_super, watch);
         light = false;
         PQPS_STAMP_VALUE(a, g, 4, (uint64_t)spins + 1);
         if (!(left & 1u) && !sum_out) {
@@ -1667,7 +1672,7 @@ __device__ __forceinline__ bool settle_group(CArgs &a, const Extent &ex, uint64_
 // lane of spills, 1 - 1.5 us on every ID query.  Once the missing sums are out (first half) nothing has to be waited
 // for any more: every deferred group's count words are complete and every group sum in front of it is published, so
 // what is in front is a plain sum, and the group's steps are expanded one at a time.
-template <bool GATHER>
+template <bool GATHER, bool NARROW = false>
 __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, const Extent &ex, uint32_t lane_in, uint32_t park) {
     uint32_t lane = lane_in;
     asm volatile("" : "+v"(lane));                                  // (keeps this cold code's address arithmetic out of the callers' registers)
@@ -1745,7 +1750,7 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
                 const uint32_t st = (uint32_t)__builtin_ctzll(rest);
                 const uint32_t cwi = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)st);
                 const uint64_t step = g * kGroupSteps + st;
-                if (word_form(a, cwi) == FORM_TINY) {               // 1 - kTinyIds matches: in the step's tiny word
+                if (!NARROW && word_form(a, cwi) == FORM_TINY) {    // 1 - kTinyIds matches: in the step's tiny word
                     if (r.pending) ring_flush(a, ring, r, lane, r.pending);
                     const uint32_t n = cwi & kCountMask;
                     uint64_t t = ld_sc1(a.tiny + step);
@@ -1762,7 +1767,7 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
                     r.pos += n;
                     continue;
                 }
-                if (word_form(a, cwi) == FORM_DIRECT) {             // 16-bit entries in its slot: a copy (every lane: this step's limit and offset)
+                if (!NARROW && word_form(a, cwi) == FORM_DIRECT) {  // 16-bit entries in its slot: a copy (every lane: this step's limit and offset)
                     if (r.pending) ring_flush(a, ring, r, lane, r.pending);
                     const uint32_t n = cwi & kCountMask;
                     const uint64_t room = r.pos < a.out_cap ? a.out_cap - r.pos : 0ull;
@@ -1786,7 +1791,7 @@ __device__ __forceinline__ void recover_deferred(CArgs &a, FusedShared &sh, cons
 
 // An expander workgroup.  Among the scan tiles: four independent waves, one group each.  Behind the last tile:
 // one group, its leader wave settles it and hands count words and output slot to the other three through LDS.
-template <bool GATHER, bool LOOPED = false>                     // LOOPED: called again for further groups -- every wave reaches the barrier
+template <bool GATHER, bool LOOPED = false, bool NARROW = false>   // LOOPED: called again for further groups -- every wave reaches the barrier
 __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, const Extent &ex, const Role &role) {
     const uint32_t lane = threadIdx.x & 63, wave = uniform_u32(threadIdx.x >> 6);
     const bool shared = role.kind == ROLE_EXPAND_GROUP;             // uniform for the workgroup
@@ -1834,7 +1839,7 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
         // (gather: the whole grid is resident at once, so a wait can only fail if a tile never ran -- no second
         // chance through the recovery pass there, the wait is long and its failure sets the status word)
         LeaderPrefetch lp{&sh, wave, pre, pre_mask};
-        ok = settle_group<kNearGroups>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, tiny_words, psum, GATHER, (!GATHER && shared) ? &lp : nullptr);
+        ok = settle_group<kNearGroups, NARROW>(a, ex, g, lane, GATHER ? kRecoverSpins : a.spin_limit, false, cw, tiny_words, psum, GATHER, (!GATHER && shared) ? &lp : nullptr);
         pre = lp.pre;
         pre_mask = lp.mask;
         __builtin_amdgcn_s_setprio(0);
@@ -1866,11 +1871,11 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
     // their entries from the look that settled the group (gather: every part's leader settles for itself -- its part's steps).
     uint64_t tiny_span = 0;
     if (leader) tiny_span = !GATHER ? ~0ull : (((1ull << (kGroupSteps / kGatherParts)) - 1ull) << (part * (kGroupSteps / kGatherParts)));
-    if (ok) expand_range<GATHER>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask, tiny_span, tiny_words);
+    if (ok) expand_range<GATHER, NARROW>(a, sh, ex, g, lane, c0, c1, wave, cnts, group_off, pre, pre_mask, tiny_span, tiny_words);
     PQPS_STAMP_GROUP_MAX(a, g, 3);
     // the last group's leader looks after the groups others gave up on (if any), once all of them are past their waits
     if constexpr (!GATHER)
-        if (leader && g + 1 == ex.groups && expanders_past_their_wait(a, ex.groups, lane)) recover_deferred<GATHER>(a, sh, ex, lane, wave);
+        if (leader && g + 1 == ex.groups && expanders_past_their_wait(a, ex.groups, lane)) recover_deferred<GATHER, NARROW>(a, sh, ex, lane, wave);
 }
 
 // Generic scan: any predicate; scan (full steps vectorised) or gather (always guarded).
@@ -2246,7 +2251,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? (W0 + W1 + W2 >= 12 ? 7 
         zero_other_ctl(a);
         const Extent ex = scan_extent<false>(a);
         const Role role = fused_role<kGroupSteps / TS>(a, (uint32_t)ex.groups);
-        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(args_for_expanders(), sh, ex, role); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false, false, (W0 == 1)>(args_for_expanders(), sh, ex, role); return; }
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step = (uint64_t)role.index * TS + wv;
         SumDuty duty;
@@ -2319,7 +2324,7 @@ __global__ __launch_bounds__(kBlock, MODE == MODE_IDS ? PQPS_CHAIN_WGS : 1) void
 #ifdef PQPS_NO_EXPAND   /* experiments: what the scan tiles cost when the kernel holds nothing else (no results) */
         if (role.kind >= ROLE_EXPAND_QUAD) return;
 #else
-        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false>(args_for_expanders(), sh, ex, role); return; }
+        if (role.kind >= ROLE_EXPAND_QUAD) { expander_workgroup<false, false, (W0 == 1)>(args_for_expanders(), sh, ex, role); return; }
 #endif
         if (role.kind != ROLE_SCAN || (uint64_t)role.index * TS >= ex.steps) return;
         const uint64_t step0 = (uint64_t)role.index * TS + (uint64_t)wv * S;

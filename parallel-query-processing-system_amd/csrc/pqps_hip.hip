@@ -939,7 +939,6 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         // PQPS_LIST_MAX (tests): 0 = no step leaves entries in its slot (bit masks / the list area for every step), 128 = up to a full slot
         static const long env_max = [] { const char *e = getenv("PQPS_LIST_MAX"); return e ? strtol(e, nullptr, 0) : -1l; }();
         const uint32_t m0 = ctx->opt_list_max >= 0 ? (uint32_t)ctx->opt_list_max : (env_max >= 0 ? (uint32_t)env_max : kListDefault);
-        const uint32_t m1 = ctx->opt_list_max_u8 >= 0 ? (uint32_t)ctx->opt_list_max_u8 : 0u;
         // PQPS_TINY_MAX (tests): 0 = no step leaves its entries in a tiny word
         static const long env_tiny = [] { const char *e = getenv("PQPS_TINY_MAX"); return e ? strtol(e, nullptr, 0) : -1l; }();
         const uint32_t t0 = ctx->opt_tiny_max >= 0 ? (uint32_t)ctx->opt_tiny_max : (env_tiny >= 0 ? (uint32_t)env_tiny : kTinyIds);
@@ -950,7 +949,7 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
         for (uint32_t c = 0; c < a.n_cols; c++) narrow = narrow && a.width_log2[c] == 0;
         if (narrow && ctx->opt_tiny_max < 0 && env_tiny < 0) a.tiny_max = 0;
         a.list_max = m0 < kListIds ? m0 : kListIds;
-        a.list_max_u8 = m1 < kListIds ? m1 : kListIds;
+        a.list_max_u8 = 0;                                           // (the kernels of 1-byte predicates carry neither form: step_form)
     }
     a.status = ctx->status_dev;
     a.out_ids = out_ids; a.out_cap = out_cap; a.out_count = out_count;
@@ -1190,7 +1189,7 @@ int pqps_ctx_set_option(pqps_ctx *ctx, const char *name, long value) {
     if (!ctx || !name) return fail(PQPS_EINVAL, "NULL argument");
     struct { const char *name; long *slot; } opts[] = {
         {"list16", &ctx->opt_list16}, {"list16_min", &ctx->opt_list16_min}, {"list16_min_u8", &ctx->opt_list16_min_u8},
-        {"list_max", &ctx->opt_list_max}, {"list_max_u8", &ctx->opt_list_max_u8}, {"tiny_max", &ctx->opt_tiny_max},
+        {"list_max", &ctx->opt_list_max}, {"tiny_max", &ctx->opt_tiny_max},
         {"expand_lag", &ctx->opt_expand_lag}, {"sum_lag", &ctx->opt_sum_lag}, {"tune", &ctx->opt_tune},
     };
     for (auto &o : opts)
