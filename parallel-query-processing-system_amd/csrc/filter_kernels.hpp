@@ -90,7 +90,7 @@ struct EvalArgs {
     uint32_t spin_limit;             // polls before an expander leaves its group to the recovery pass
     // (32-bit fields: a 16-bit kernel argument picked by a run-time index is fetched with a VECTOR load, on the tile's path)
     uint32_t list16_min, list16_min_u8;   // a step with MORE matches than this leaves a 16-bit row list (_u8: widest predicate column 1 byte wide)
-    uint32_t list_max, list_max_u8;       // a step with at most this many matches leaves them as 16-bit entries in its slot (<= kListIds)
+    uint32_t list_max, list_max_u8;       // a step with at most this many matches leaves them as 16-bit entries in its slot (<= kListIds; _u8: unused, 0)
     uint32_t tiny_max;                    // a step with at most this many matches (<= kTinyIds; 0: never) leaves them in its tiny word
     uint32_t tune;                   // A/B switches of tuning runs (PQPS_TUNE): bit 0 = no second look ahead of early expander waves
     uint32_t accumulate;             // gather: append behind *out_count
@@ -843,9 +843,9 @@ __device__ __forceinline__ void store_list(CArgs &a, uint16_t *stage, uint64_t s
         st_sc1((uint64_t *)((lane < 16u ? a.slots : a.slots_hi) + step * kSlotWords) + (lane & 15u), ((const uint64_t *)stage)[lane]);
 }
 
-// A step with more than a.list16_min matches (host: 8) leaves them as a list of another kind when the launch has a list
-// area (a.lists): 16-bit row numbers inside the step, ascending, at lists[step * 1024 ...] -- 2 bytes per match instead of
-// a 128-byte slot with a bit mask or a packed 10-bit list.  Turning a dense bit mask into IDs costs the expander ~400 vector instructions per step (64 rows at a time:
+// A step with more matches than its slot takes (a.list_max, and more than a.list16_min) leaves them as a list of another kind when
+// the launch has a list area (a.lists): 16-bit row numbers inside the step, ascending, at lists[step * 1024 ...] -- 2 bytes per match
+// instead of a 128-byte bit mask.  Turning a dense bit mask into IDs costs the expander ~400 vector instructions per step (64 rows at a time:
 // read the bits of the 64 rows into a scalar pair, rank, store) and the expanders behind the last tile have nothing
 // to hide them under: `risk_level > 1` (43 % of 100 M rows) took 225 us, 160 of them after the last tile.  The
 // scan tile's vector units idle while it waits for memory; it ranks its own matches (two wave scans for the chunks'
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ uint32_t prefetch_own_steps(CArgs &a, FusedShared &sh
 // The LEADER's look ahead: it reads all 64 count words anyway.  A group with few matches (<= kSoloIds: the leader
 // will expand it alone) and at most 16 non-empty steps gets those steps' slots requested in the packed order the
 // sparse branch of expand_range uses (slot k = the k-th non-empty step) -> returns 2 << 16 and the steps in `mask`;
-// otherwise the leader's own quarter as in prefetch_own_steps.
+// otherwise the leader's own quarter (its 16 steps) as in prefetch_own_steps.
 // (`c`: lane l holds the count word of step l of the group, all 64 known to carry this query's epoch)
 __device__ __forceinline__ uint32_t leader_prefetch_with(CArgs &a, FusedShared &sh, uint64_t g, uint32_t lane, uint32_t park,
                                                          uint32_t c, uint64_t &mask) {
@@ -1798,7 +1798,7 @@ __device__ __forceinline__ void expander_workgroup(CArgs &a, FusedShared &sh, co
     const bool leader = !shared || wave == 0;
     // Gather (index mode): few groups, often dense, and every step of the expansion is a chain of memory latencies (bit mask,
     // candidate numbers, stores) -- a workgroup takes a SIXTEENTH of a group (kGatherParts: 4 steps, one per wave), so that a
-    // probe is spread over sixteen times as many waves (a quarter per workgroup, 4 steps per wave: `sudo_used = TRUE AND
+    // probe is spread over sixteen times as many waves (with a quarter of a group per workgroup, 4 steps per wave: `sudo_used = TRUE AND
     // risk_level > 3` over 4.4 M candidates 140 us); role.index counts parts.  Every part's leader settles the group for itself
     // (and publishes its sum: the same value every time).
     const uint32_t part = GATHER ? role.index % kGatherParts : 0u;

@@ -924,9 +924,9 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.lists = (gather || !lists_wanted) ? nullptr : ensure_lists(ctx, steps);
     {
         // Measured at 100 M rows (S1 / Q_A / Q_B / risk_level > 2, us per query): from 103 matches on 58.7 / 91.7 / 108.6 / 91.7, from 33
-        // 57.8 / 90.6 / 104.6 / 91.8, from 9 58.3 / 88.8 / 104.4 / 91.5, every non-empty step 60.7 / 88.7 / 104.2 / 91.6: the 10-bit list
-        // inside the step's 128-byte slot stays for the steps of a sparse answer (their slots are fetched while the leader
-        // still waits for the sums in front).  1-byte columns: their tiles have no instruction slots to spare (a lone u8
+        // 57.8 / 90.6 / 104.6 / 91.8, from 9 58.3 / 88.8 / 104.4 / 91.5, every non-empty step 60.7 / 88.7 / 104.2 / 91.6 (round 3; the steps below
+        // the threshold then left 10-bit lists in their slots, now 16-bit entries or tiny words -- up to list_max matches a step
+        // never comes here: step_form).  1-byte columns: their tiles have no instruction slots to spare (a lone u8
         // column with 7 % matches: 47.5 us with bit masks, 56 - 58 with lists).
         static const uint32_t from = [] { const char *e = tuning_env("PQPS_LIST16_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 8u; }();
         static const uint32_t from_u8 = [] { const char *e = tuning_env("PQPS_LIST16_MIN_U8"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 1024u; }();
