@@ -789,7 +789,7 @@ def main():
                    "timed_regions": len(regions), "value_is": "median over the timed regions of `steps` queries each (roofline.value_spread_*)",
                    "pipelining": ((f"{args.engine_threads} host thread(s) x {args.engine_in_flight} asynchronous tickets outstanding over {copies} engines "
                                    "(copies of the table, alternated); every engine runs its queries on two lanes = two HIP streams "
-                                   "(one for tables of 268 M rows and more): the tail of one launch under the scan tiles of the next")
+                                   "(one for tables of 537 M rows and more): the tail of one launch under the scan tiles of the next")
                                   if eng is not None else
                                   ("two queries in flight, each whole on a stream of its own: the tail of query k's launch (+ its exchange) under the scan tiles of query k+1"
                                    if shim["pipelined"] else "none: the queries back to back on one stream")),

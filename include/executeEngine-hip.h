@@ -130,7 +130,7 @@ struct engineS *initializeEngineSyntheticHIP(unsigned long long num_rows, unsign
 
 /* ---- asynchronous queries: several in flight, results left on the device -----------------------------------------
  * The engine's table has LANES (default 4, PQPS_ENGINE_LANES): result buffers + a slot of the table's query stream
- * (pqps_qstream: two launches in flight on two HIP streams, one for tables of 268 M rows and more).  Every SELECT /
+ * (pqps_qstream: two launches in flight on two HIP streams, one for tables of 537 M rows and more).  Every SELECT /
  * COUNT takes a lane for its device phase -- concurrent callers of the synchronous functions (the reference's OpenMP
  * driver, QPEOMP.c:234-291) therefore overlap on the device -- and a caller can keep several queries in flight itself:
  *   t = executeQuerySelectAsyncHIP(engine, where)     enqueues the query (blocks only while every lane is taken)

@@ -294,7 +294,7 @@ int pqps_qstream_destroy(pqps_qstream *q);
  * other threads do the same on other slots (the reference's OpenMP driver, QPEOMP.c:234-291).  Issuing calls on one
  * query stream must not overlap (the caller serialises them, e.g. under a mutex: they take microseconds);
  * pqps_qstream_wait may run concurrently with anything.  A slot is reused only after its query has been waited for.
- * Tables of 268 M rows and more use ONE lane (their launches keep expanders among the scan tiles, the tail is a few
+ * Tables of 537 M rows and more use ONE lane (their launches keep expanders among the scan tiles, the tail is a few
  * percent of the launch, and two launches side by side lose more than the overlap gains). */
 int pqps_qstream_scan_slot(pqps_qstream *q, uint32_t slot, const pqps_column *cols, uint32_t n_cols, uint64_t n_rows, uint32_t id_base,
                            const pqps_predicate *pred, uint32_t *out_ids, uint64_t out_capacity, uint64_t *out_count, void *scan_stream);

@@ -708,14 +708,15 @@ typedef void (*eval_fn)(const EvalArgs);
 // chain kernels exist with 1 step per iteration and (narrow shapes) with several, and in three evaluator variants:
 // EV 0 ballots (every shape), EV 1 one comparison on one column on the vector unit (single-column shapes), EV 2 a chain
 // on the vector unit (shapes of up to 8 bytes per row whose widest column has 4)
-constexpr uint64_t kInterleaveFromGroups = 4096;                    // from this many groups (268 M rows) on the expanders run among the scan tiles, see expand_lag()
+constexpr uint64_t kInterleaveFromGroups = 8192;                    // from this many groups (537 M rows) on the expanders run among the scan tiles, see expand_lag()
+constexpr uint64_t kListAreaBelowGroups = 4096;                     // below this many groups (268 M rows) ID scans have a list area, and the S1 shape takes its vector-unit chain kernel
 constexpr bool valu_chain_shape(int a, int b, int c) { return a <= 4 && a + b + c <= 8; }
 // ... and where it is the default.  A/B runs on one box (us per launch, ballots / vector unit): S1 = (2,1,0) as ID list at
 // 100 M rows 59.4 / 57.4, at 1 G rows 496 / 496, as COUNT(*) at 1 G rows 438 / 468; Q_B = (4,1,0) as ID list 103 / 113 (its
 // tile path spills at 64 VGPRs), at 1 G rows 901 / 959.  So: the u16 + u8 shape, ID output, below the size from which the
 // expanders run among the tiles.
 inline bool valu_chain_default(uint32_t w0, uint32_t w1, uint32_t w2, int mode, uint64_t n_rows) {
-    return mode == MODE_IDS && w0 == 2 && w1 == 1 && w2 == 0 && n_rows < kInterleaveFromGroups * (uint64_t)kGroupSteps * kStepRows;
+    return mode == MODE_IDS && w0 == 2 && w1 == 1 && w2 == 0 && n_rows < kListAreaBelowGroups * (uint64_t)kGroupSteps * kStepRows;
 }
 
 template <int MODE, int A, int B, int C, int S, bool NT>
@@ -841,6 +842,8 @@ uint32_t expand_sum_lag(const pqps_ctx *ctx, uint32_t tiles_per_group) {
 uint32_t expand_lag(const pqps_ctx *ctx, uint32_t tiles_per_group, uint64_t groups) {
     static const char *env = getenv("PQPS_EXPAND_LAG");
     if (env) return (uint32_t)strtoul(env, nullptr, 10);
+    // (round 4, with the copied entries: at 530 M rows all behind the last tile is level for S1 / Q_A / Q_B and 2 - 8 % faster for the wide, the
+    // narrow and the dense shapes; at 700 M rows among the tiles wins S1 and Q_B by 2 %, at 1 G rows S1 by 7 %, Q_A / Q_B by 3 %)
     if (groups < kInterleaveFromGroups) return 0x7FFFFFFFu;         // all behind the last tile
     // behind the sums it needs: at 1 G rows (sum lag / expander lag in groups) 150 / 300: Q_A 686 us, Q_B 918;
     // 300 / 600: 699, 938; 300 / 450: 669, 903
@@ -914,13 +917,13 @@ int run_filter(pqps_ctx *ctx, eval_fn k1, EvalArgs &a, uint64_t rows, int mode, 
     a.ctl = ctx->ctl + half * kCtlWords;
     a.zctl = ctx->ctl + (half ^ 1) * kCtlWords;
     a.base_slot = ctx->base_slot;
-    // The list area serves launches whose expanders run BEHIND the last tile (below kInterleaveFromGroups groups): there the
+    // The list area serves the smaller launches whose expanders run BEHIND the last tile (below kListAreaBelowGroups groups): there the
     // expansion is the launch's tail and a copy is what it should be (`risk_level > 1` at 100 M rows 161 -> 130 us, `> 2`
     // 101 -> 91; few-percent answers level).  Among the tiles -- 268 M rows and more -- the expansion hides under the scan
     // whatever form the matches were left in, and the lists only add traffic and a longer tile: same-process A/B at 1 G rows
     // on two boxes, lists / none: S1 500 / 493 and 501 / 484 us, Q_A 800 / 753 and 747 / 743, Q_B 1080 / 999 and 987 / 967,
     // `risk_level > 2` 1051 / 929 and 921 / 893, `> 1` 1475 / 1254 (round 3 had compared processes, whose tables lie elsewhere).
-    const bool lists_wanted = ctx->opt_list16 >= 0 ? ctx->opt_list16 != 0 : groups < kInterleaveFromGroups;
+    const bool lists_wanted = ctx->opt_list16 >= 0 ? ctx->opt_list16 != 0 : groups < kListAreaBelowGroups;
     a.lists = (gather || !lists_wanted) ? nullptr : ensure_lists(ctx, steps);
     {
         // Measured at 100 M rows (S1 / Q_A / Q_B / risk_level > 2, us per query): from 103 matches on 58.7 / 91.7 / 108.6 / 91.7, from 33
@@ -2463,7 +2466,7 @@ int pqps_exchange_sync(pqps_exchange *x) {
 // of their time and their access windows interleave).  Each lane has its own scratch; results go to `depth` SLOTS
 // (the caller's output buffers: slot k is free again when the query that last used it has finished).
 //
-// One lane for large tables: from kInterleaveFromGroups groups on (268 M rows) the expanders run among the scan
+// One lane for large tables: from kInterleaveFromGroups groups on (537 M rows) the expanders run among the scan
 // tiles, the tail is a few percent of the launch, and two launches side by side cost more than the overlap gains
 // (1 G rows: Q_A 736 us per query with two lanes against 690 one at a time, Q_B 960 against 940).  Such queries all
 // go to lane 0, i.e. back to back on one stream; the slots still let the host run ahead.
@@ -2674,7 +2677,7 @@ int pqps_qstream_reserve(pqps_qstream *q, uint64_t n_rows) {
     for (uint32_t i = 0; i < q->lanes; i++) {
         const int rc = ensure_scratch(q->child[i], steps);
         if (rc) return rc;
-        if ((steps + kGroupSteps - 1) / kGroupSteps < kInterleaveFromGroups)
+        if ((steps + kGroupSteps - 1) / kGroupSteps < kListAreaBelowGroups)
             (void)ensure_lists(q->child[i], steps);              // (larger tables scan without lists; refused: bit masks, same results)
     }
     return PQPS_OK;
